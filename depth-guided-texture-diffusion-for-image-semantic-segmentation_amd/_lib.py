@@ -1,0 +1,82 @@
+"""ctypes binding of libdgtd.so (the C ABI declared in include/dgtd.h).
+
+There is no fallback: if the library is missing or a symbol is absent, importing/using the ops
+raises.  The product path never routes through PyTorch reference code or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgtd.so")
+
+F32, BF16 = 0, 1
+_vp, _fp, _i, _i64, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); kept in lock-step with include/dgtd.h (tests/test_abi.py parses the header)
+SIGNATURES = {
+    "dgtd_version": (_i, []),
+    "dgtd_last_error": (C.c_char_p, []),
+    "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
+    "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
+    "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
+    "dgtd_sra_attn_fwd": (_i, [_vp, _vp, _vp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dgtd_sra_attn_bwd_workspace": (_i64, [_i, _i, _i]),
+    "dgtd_sra_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _fp, _vp, _fp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+class DgtdError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the HIP ops")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise DgtdError(f"dgtd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise DgtdError("dgtd ops run only on the MI355X HIP device (tensor is on %s); "
+                            "the CPU restatement lives in oracle/ and is test infrastructure" % t.device)
+        if not t.is_contiguous():
+            raise DgtdError("dgtd ops need contiguous tensors")
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DgtdError(f"{name} failed (code {rc}): {lib.dgtd_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

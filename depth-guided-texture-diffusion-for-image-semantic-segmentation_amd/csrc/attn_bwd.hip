@@ -1,0 +1,491 @@
+// attn_bwd.hip — backward of the fused spatial-reduction attention (dQ, dK, dV), head_dim 64.
+// Gradient of twig/model/cod.py:913-917 with P recomputed from Q, K and the forward's log-sum-exp.
+//
+// Structure (key-stationary; K/V are short): a workgroup owns one (batch, head) and a chunk
+// of 32-row query tiles; wave w owns keys [32w, 32w+32) of the current 256-key slice and keeps dK^T/dV^T of
+// those keys in accumulator registers while the workgroup sweeps the query tiles.  Per query tile every
+// wave computes its S / dP tiles in BOTH orientations (rows = query and rows = key) so that each of the
+// three gradient products sums over the accumulator ROW index and can take the accumulator straight back
+// as an MFMA operand (CDNA4 guide §3): no score tile is ever transposed through memory.
+//   dV[key][d] += sum_q P[q][key]  dO[q][d]      (rows = q tile as the A operand, Z = X^T B)
+//   dK[key][d] += sum_q dS[q][key] Q[q][d]
+//   dQ^T[d][q] += sum_k K[k][d]   dS^T[k][q]     (rows = key tile as the B operand, Y = A X)
+// dQ partials of the waves are summed with LDS atomics; dK/dV leave the workgroup as fp32 global atomics
+// (one 128-B segment per half-wave, the full-rate shape) into a caller-zeroed fp32 buffer.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int SLICE = 256;  // keys per pass over the query chunk (8 waves x 32 keys)
+
+// delta[b][h][n] = sum_d dO[b][n][h*64+d] * O[b][n][h*64+d]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int N, int heads) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N, LPR = 64 / V;  // lanes per (row, head)
+  const int64_t total = (int64_t)B * N * heads;
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  const int64_t item = gid / LPR;
+  const int sub = (int)(gid % LPR);
+  float s = 0.f;
+  int64_t bn = 0; int hd = 0;
+  if (item < total) {
+    bn = item / heads; hd = (int)(item % heads);
+    const size_t off = ((size_t)bn * heads + hd) * 64 + sub * V;
+    VT a = *reinterpret_cast<const VT*>(o + off);
+    VT g = *reinterpret_cast<const VT*>(dout + off);
+#pragma unroll
+    for (int j = 0; j < V; ++j) s += (float)a[j] * (float)g[j];
+  }
+  s = group_sum(s, LPR);
+  if (item < total && sub == 0) {
+    const int64_t b = bn / N, n = bn % N;
+    delta[((size_t)b * heads + hd) * N + n] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ bf16
+// LDS (elements of bf16 unless noted):
+//   Qr[32][72], Gr[32][72]   row-major Q / dO tile (row frags, 16-B reads)
+//   Qt[64][36], Gt[64][36]   transposed tiles (col frags: 4 consecutive queries = 8 B)
+//   Kt[64][SLICE+4]          transposed K slice (col frags for dQ), read once into registers
+//   lse2[32], dlt[32] fp32; dqs[32][64] fp32 (LDS-atomic dQ tile)
+struct BwdSmemBf16 {
+  static constexpr int QS = 72, TS = 36, KTS = SLICE + 4;
+  static constexpr size_t off_Qr = 0;
+  static constexpr size_t off_Gr = off_Qr + 32 * QS * 2;
+  static constexpr size_t off_Qt = off_Gr + 32 * QS * 2;
+  static constexpr size_t off_Gt = off_Qt + 64 * TS * 2;
+  static constexpr size_t off_Kt = off_Gt + 64 * TS * 2;
+  static constexpr size_t off_lse = off_Kt + 64 * KTS * 2;
+  static constexpr size_t off_dlt = off_lse + 32 * 4;
+  static constexpr size_t off_dq = off_dlt + 32 * 4;
+  static constexpr size_t total = off_dq + 32 * 64 * 4;
+};
+
+__global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                    const float* __restrict__ delta, bf16_t* __restrict__ dq,
+                                                    float* __restrict__ dkv, int N, int Nkv, int heads, float scale,
+                                                    int qch) {
+  typedef BwdSmemBf16 L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::off_Qr);
+  bf16_t* Gr = reinterpret_cast<bf16_t*>(smem + L::off_Gr);
+  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem + L::off_Qt);
+  bf16_t* Gt = reinterpret_cast<bf16_t*>(smem + L::off_Gt);
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem + L::off_Kt);
+  float* lse2 = reinterpret_cast<float*>(smem + L::off_lse);
+  float* dlt = reinterpret_cast<float*>(smem + L::off_dlt);
+  float* dqs = reinterpret_cast<float*>(smem + L::off_dq);
+
+  const int C = heads * 64;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const float sl2 = scale * LOG2E;
+  const bf16_t* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
+  const int qt_begin = blockIdx.x * qch;
+  const int qt_end = min(qt_begin + qch, (N + 31) / 32);
+  const int nslices = (Nkv + SLICE - 1) / SLICE;
+
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int k0 = sl * SLICE;
+    const int kn = min(SLICE, Nkv - k0);           // keys in this slice
+    const int mykey = k0 + wave * 32 + r;          // this lane's key when the key sits on the lane
+    const bool wave_active = wave * 32 < kn;
+    // ---- stage K^T slice, then pull the stationary fragments into registers
+    __syncthreads();
+    for (int i = tid; i < SLICE * 8; i += nthr) {
+      int key = i >> 3, ch = i & 7;
+      bf16x8 kk;
+      if (key < kn) kk = *reinterpret_cast<const bf16x8*>(kvb + (size_t)(k0 + key) * 2 * C + ch * 8);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk[j] = (bf16_t)0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Kt[(ch * 8 + j) * L::KTS + key] = kk[j];
+    }
+    __syncthreads();
+    bf16x8 kf[4], vf[4];     // row frags: lane (key r, half h): K/V[key][16s+8h .. +7]
+    bf16x8 kcf[2][2];        // col frags for dQ: [s2][nb], lane (d = nb*32+r, h)
+    {
+      const bool kok = wave_active && (wave * 32 + r) < kn;
+      const bf16_t* kp = kvb + (size_t)mykey * 2 * C + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
+        else
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const bf16_t* p = Kt + (nb * 32 + r) * L::KTS + wave * 32 + 16 * s2 + 4 * h;
+          bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { kcf[s2][nb][j] = lo[j]; kcf[s2][nb][4 + j] = hi[j]; }
+        }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+      const int q0 = qt * 32;
+      __syncthreads();  // previous tile fully consumed
+      // ---- stage Q (threads 0..255) and dO (threads 256..511, or the same threads when the block is small)
+      for (int i = tid; i < 512; i += nthr) {
+        const int which = i >> 8, j8 = i & 255, row = j8 >> 3, ch = j8 & 7;
+        const bf16_t* src = (which ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8;
+        bf16x8 v;
+        if (q0 + row < N) v = *reinterpret_cast<const bf16x8*>(src);
+        else
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+        bf16_t* rowm = which ? Gr : Qr;
+        bf16_t* trn = which ? Gt : Qt;
+        *reinterpret_cast<bf16x8*>(rowm + row * L::QS + ch * 8) = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) trn[(ch * 8 + j) * L::TS + row] = v[j];
+      }
+      for (int i = tid; i < 32; i += nthr) {
+        const bool ok = (q0 + i) < N;
+        const size_t o = ((size_t)b * heads + hd) * N + q0 + i;
+        lse2[i] = ok ? lse[o] * LOG2E : INFINITY;   // +inf -> P = exp2(-inf) = 0 for padded query rows
+        dlt[i] = ok ? delta[o] : 0.f;
+      }
+      for (int i = tid; i < 32 * 64; i += nthr) dqs[i] = 0.f;
+      __syncthreads();
+
+      if (wave_active) {
+        bf16x8 qf[4], gf[4];  // row frags of the Q / dO tile: lane (row r, half h)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qf[s] = *reinterpret_cast<const bf16x8*>(Qr + r * L::QS + 16 * s + 8 * h);
+          gf[s] = *reinterpret_cast<const bf16x8*>(Gr + r * L::QS + 16 * s + 8 * h);
+        }
+        const bool key_ok_lane = (wave * 32 + r) < kn;
+        // ===== orientation 1: rows = query, lane = key  -> dV, dK
+        {
+          f32x16 sA, pA;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
+            pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qi = mfma_row(i, h);
+            float p = key_ok_lane ? exp2f(sA[i] * sl2 - lse2[qi]) : 0.f;
+            sA[i] = p;                                   // P
+            pA[i] = p * (pA[i] - dlt[qi]) * scale;       // dS
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf, df;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              const bf16_t* gp = Gt + (nb * 32 + r) * L::TS + 16 * s2 + 4 * h;
+              const bf16_t* qp = Qt + (nb * 32 + r) * L::TS + 16 * s2 + 4 * h;
+              bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp), g1 = *reinterpret_cast<const bf16x4*>(gp + 8);
+              bf16x4 q0v = *reinterpret_cast<const bf16x4*>(qp), q1v = *reinterpret_cast<const bf16x4*>(qp + 8);
+              bf16x8 gb, qb;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { gb[j] = g0[j]; gb[4 + j] = g1[j]; qb[j] = q0v[j]; qb[4 + j] = q1v[j]; }
+              dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+              dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+            }
+          }
+        }
+        // ===== orientation 2: rows = key, lane = query  -> dQ
+        {
+          f32x16 sB, pB;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sB[i] = 0.f; pB[i] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sB, 0, 0, 0);   // S^T[key][q]
+            pB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], gf[s], pB, 0, 0, 0);   // dP^T[key][q]
+          }
+          const float l2 = lse2[r], dl = dlt[r];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const bool kok = (wave * 32 + mfma_row(i, h)) < kn;
+            float p = kok ? exp2f(sB[i] * sl2 - l2) : 0.f;
+            pB[i] = p * (pB[i] - dl) * scale;            // dS^T
+          }
+          f32x16 dqa[2];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { dqa[0][i] = 0.f; dqa[1][i] = 0.f; }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 df;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) df[j] = (bf16_t)pB[8 * s2 + j];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              dqa[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcf[s2][nb], df, dqa[nb], 0, 0, 0);  // dQ^T[d][q]
+          }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[r * 64 + nb * 32 + mfma_row(i, h)], dqa[nb][i]);
+        }
+      }
+      __syncthreads();
+      // ---- dQ tile out (accumulate over key slices through global memory: same workgroup, no race)
+      for (int i = tid; i < 32 * 8; i += nthr) {
+        const int row = i >> 3, ch = i & 7;
+        if (q0 + row < N) {
+          bf16_t* dst = dq + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8;
+          bf16x8 o;
+          if (sl > 0) {
+            bf16x8 prev = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)prev[j] + dqs[row * 64 + ch * 8 + j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)dqs[row * 64 + ch * 8 + j];
+          }
+          *reinterpret_cast<bf16x8*>(dst) = o;
+        }
+      }
+    }
+    // ---- flush dK / dV of this wave's keys (fp32 atomics; lanes r = 32 consecutive d)
+    if (wave_active) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = wave * 32 + mfma_row(i, h);
+          if (key < kn) {
+            float* p = dkv + ((size_t)b * Nkv + k0 + key) * 2 * C + hd * 64 + nb * 32 + r;
+            atomicAdd(p, dk[nb][i]);
+            atomicAdd(p + C, dv[nb][i]);
+          }
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ fp32
+// LDS (floats): Qr[32][65], Gr[32][65] (row-major, padded: conflict-free column reads), Ks[SLICE][64],
+//               lse2[32], dlt[32], dqs[32][64]
+struct BwdSmemF32 {
+  static constexpr int QS = 65;
+  static constexpr size_t off_Qr = 0;
+  static constexpr size_t off_Gr = off_Qr + 32 * QS * 4;
+  static constexpr size_t off_Ks = off_Gr + 32 * QS * 4;
+  static constexpr size_t off_lse = off_Ks + (size_t)SLICE * 64 * 4;
+  static constexpr size_t off_dlt = off_lse + 32 * 4;
+  static constexpr size_t off_dq = off_dlt + 32 * 4;
+  static constexpr size_t total = off_dq + 32 * 64 * 4;
+};
+
+__global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, const float* __restrict__ kv,
+                                                   const float* __restrict__ dout, const float* __restrict__ lse,
+                                                   const float* __restrict__ delta, float* __restrict__ dq,
+                                                   float* __restrict__ dkv, int N, int Nkv, int heads, float scale,
+                                                   int qch) {
+  typedef BwdSmemF32 L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qr = reinterpret_cast<float*>(smem + L::off_Qr);
+  float* Gr = reinterpret_cast<float*>(smem + L::off_Gr);
+  float* Ks = reinterpret_cast<float*>(smem + L::off_Ks);
+  float* lse2 = reinterpret_cast<float*>(smem + L::off_lse);
+  float* dlt = reinterpret_cast<float*>(smem + L::off_dlt);
+  float* dqs = reinterpret_cast<float*>(smem + L::off_dq);
+
+  const int C = heads * 64;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const float sl2 = scale * LOG2E;
+  const float* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
+  const int qt_begin = blockIdx.x * qch;
+  const int qt_end = min(qt_begin + qch, (N + 31) / 32);
+  const int nslices = (Nkv + SLICE - 1) / SLICE;
+
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int k0 = sl * SLICE;
+    const int kn = min(SLICE, Nkv - k0);
+    const bool wave_active = wave * 32 < kn;
+    __syncthreads();
+    for (int i = tid; i < SLICE * 16; i += nthr) {
+      int key = i >> 4, ch = i & 15;
+      f32x4 kk;
+      if (key < kn) kk = *reinterpret_cast<const f32x4*>(kvb + (size_t)(k0 + key) * 2 * C + ch * 4);
+      else { kk[0] = kk[1] = kk[2] = kk[3] = 0.f; }
+      *reinterpret_cast<f32x4*>(Ks + key * 64 + ch * 4) = kk;
+    }
+    __syncthreads();
+    // stationary K/V values of this lane's key: element tt <-> d = 2*tt + h
+    float kf[32], vf[32];
+    {
+      const bool kok = (wave * 32 + r) < kn;
+      const float* kp = kvb + (size_t)(k0 + wave * 32 + r) * 2 * C;
+#pragma unroll
+      for (int tt = 0; tt < 32; tt += 2) {
+        f32x4 a, v;
+        if (kok) { a = *reinterpret_cast<const f32x4*>(kp + 2 * tt); v = *reinterpret_cast<const f32x4*>(kp + C + 2 * tt); }
+        else { a[0] = a[1] = a[2] = a[3] = 0.f; v = a; }
+        kf[tt] = h ? a[1] : a[0]; kf[tt + 1] = h ? a[3] : a[2];
+        vf[tt] = h ? v[1] : v[0]; vf[tt + 1] = h ? v[3] : v[2];
+      }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+      const int q0 = qt * 32;
+      __syncthreads();
+      for (int i = tid; i < 1024; i += nthr) {
+        const int which = i >> 9, j16 = i & 511, row = j16 >> 4, ch = j16 & 15;
+        const float* src = (which ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 4;
+        f32x4 v;
+        if (q0 + row < N) v = *reinterpret_cast<const f32x4*>(src);
+        else { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        float* dst = (which ? Gr : Qr) + row * L::QS + ch * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = v[j];
+      }
+      for (int i = tid; i < 32; i += nthr) {
+        const bool ok = (q0 + i) < N;
+        const size_t o = ((size_t)b * heads + hd) * N + q0 + i;
+        lse2[i] = ok ? lse[o] * LOG2E : INFINITY;
+        dlt[i] = ok ? delta[o] : 0.f;
+      }
+      for (int i = tid; i < 32 * 64; i += nthr) dqs[i] = 0.f;
+      __syncthreads();
+
+      if (wave_active) {
+        const bool key_ok_lane = (wave * 32 + r) < kn;
+        const float* qrow = Qr + r * L::QS + h;   // Q[q0+r][2tt+h]
+        const float* grow = Gr + r * L::QS + h;
+        // ===== orientation 1: rows = query, lane = key
+        {
+          f32x16 sA, pA;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+#pragma unroll
+          for (int tt = 0; tt < 32; ++tt) {
+            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[2 * tt], kf[tt], sA, 0, 0, 0);
+            pA = __builtin_amdgcn_mfma_f32_32x32x2f32(grow[2 * tt], vf[tt], pA, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qi = mfma_row(i, h);
+            float p = key_ok_lane ? exp2f(sA[i] * sl2 - lse2[qi]) : 0.f;
+            sA[i] = p;
+            pA[i] = p * (pA[i] - dlt[qi]) * scale;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qi = mfma_row(i, h);
+            const float* gp = Gr + qi * L::QS + r;
+            const float* qp = Qr + qi * L::QS + r;
+            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[i], gp[0], dv[0], 0, 0, 0);
+            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[i], gp[32], dv[1], 0, 0, 0);
+            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pA[i], qp[0], dk[0], 0, 0, 0);
+            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pA[i], qp[32], dk[1], 0, 0, 0);
+          }
+        }
+        // ===== orientation 2: rows = key, lane = query
+        {
+          f32x16 sB, pB;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sB[i] = 0.f; pB[i] = 0.f; }
+#pragma unroll
+          for (int tt = 0; tt < 32; ++tt) {
+            sB = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tt], qrow[2 * tt], sB, 0, 0, 0);
+            pB = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[tt], grow[2 * tt], pB, 0, 0, 0);
+          }
+          const float l2 = lse2[r], dl = dlt[r];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const bool kok = (wave * 32 + mfma_row(i, h)) < kn;
+            float p = kok ? exp2f(sB[i] * sl2 - l2) : 0.f;
+            pB[i] = p * (pB[i] - dl) * scale;
+          }
+          f32x16 dqa[2];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { dqa[0][i] = 0.f; dqa[1][i] = 0.f; }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float* kp = Ks + (wave * 32 + mfma_row(i, h)) * 64 + r;   // K[key][d = nb*32 + r]
+            dqa[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[0], pB[i], dqa[0], 0, 0, 0);
+            dqa[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[32], pB[i], dqa[1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[r * 64 + nb * 32 + mfma_row(i, h)], dqa[nb][i]);
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 32 * 16; i += nthr) {
+        const int row = i >> 4, ch = i & 15;
+        if (q0 + row < N) {
+          float* dst = dq + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 4;
+          f32x4 o = *reinterpret_cast<const f32x4*>(dqs + row * 64 + ch * 4);
+          if (sl > 0) { f32x4 prev = *reinterpret_cast<const f32x4*>(dst); o += prev; }
+          *reinterpret_cast<f32x4*>(dst) = o;
+        }
+      }
+    }
+    if (wave_active) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = wave * 32 + mfma_row(i, h);
+          if (key < kn) {
+            float* p = dkv + ((size_t)b * Nkv + k0 + key) * 2 * C + hd * 64 + nb * 32 + r;
+            atomicAdd(p, dk[nb][i]);
+            atomicAdd(p + C, dv[nb][i]);
+          }
+        }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) { return (int64_t)B * N * heads * sizeof(float); }
+
+extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse,
+                                 void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
+                                 dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && N > 0 && Nkv > 0 && heads > 0, "sra_attn_bwd: bad sizes B=%d N=%d Nkv=%d heads=%d", B, N, Nkv, heads);
+  DGTD_REQUIRE(dt == DGTD_F32 || dt == DGTD_BF16, "sra_attn_bwd: bad dtype %d", (int)dt);
+  hipStream_t st = (hipStream_t)s;
+  float* delta = (float*)workspace;
+  const int64_t items = (int64_t)B * N * heads;
+  if (dt == DGTD_BF16) {
+    hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, heads);
+  } else {
+    hipLaunchKernelGGL((attn_delta_kernel<float>), dim3((unsigned)cdiv(items * 16, 256)), dim3(256), 0, st, (const float*)out, (const float*)dout, delta, B, N, heads);
+  }
+  DGTD_CHECK_LAUNCH("attn_delta");
+  const int qtiles = (int)cdiv(N, 32);
+  // query tiles per workgroup: enough workgroups to fill 256 CUs, few enough dK/dV flushes
+  int qch = 1;
+  while (qch < 32 && cdiv(qtiles, qch * 2) * B * heads >= 512) qch *= 2;
+  const int nwaves = (int)cdiv(std::min(Nkv, SLICE), 32);
+  dim3 grid((unsigned)cdiv(qtiles, qch), heads, B), block(64 * nwaves);
+  if (dt == DGTD_BF16) {
+    hipLaunchKernelGGL(sra_bwd_bf16, grid, block, BwdSmemBf16::total, st, (const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, lse, delta, (bf16_t*)dq, dkv_f32, N, Nkv, heads, scale, qch);
+  } else {
+    hipLaunchKernelGGL(sra_bwd_f32, grid, block, BwdSmemF32::total, st, (const float*)q, (const float*)kv, (const float*)dout, lse, delta, (float*)dq, dkv_f32, N, Nkv, heads, scale, qch);
+  }
+  DGTD_CHECK_LAUNCH("sra_attn_bwd");
+  return 0;
+}

@@ -1,0 +1,598 @@
+"""HIP-backed modules.  Layout policy: everything token-major / NHWC ([B, H*W, C]) inside the two
+trunks, so LayerNorm, attention and the depthwise convs see contiguous channel rows and no
+NCHW<->NHWC permute copies exist on the path; strided k==s convolutions (ConvNeXt stem/downsample,
+the attention spatial-reduction conv) are patchify + GEMM.
+
+Reference citations are to /root/reference/twig/model/cod.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+LATENT = 24
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class DropPath(nn.Module):
+    """Stochastic depth, timm 0.6.13 semantics (cod.py:816): identity in eval or when p == 0."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+
+def _init_weights(m: nn.Module) -> None:
+    """cod.py:1401-1414."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, (nn.LayerNorm, LayerNorm)):
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.Conv2d):
+        fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+def _patchify(x: torch.Tensor, H: int, W: int, k: int) -> torch.Tensor:
+    """tokens [B, H*W, C] -> [B, (H/k)*(W/k), C*k*k] in (c, ky, kx) order = Conv2d weight.flatten(1) order."""
+    B, _, Cc = x.shape
+    x = x.view(B, H // k, k, W // k, k, Cc).permute(0, 1, 3, 5, 2, 4)
+    return x.reshape(B, (H // k) * (W // k), Cc * k * k)
+
+
+def _tokens_to_nchw(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    B, _, Cc = x.shape
+    return x.view(B, H, W, Cc).permute(0, 3, 1, 2)
+
+
+class LayerNorm(nn.Module):
+    """cod.py:1025-1049 and nn.LayerNorm.  Both data formats normalise the channel dim; in the token-major
+    layout of this package that is always the last dim, so one kernel serves both."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps, self.data_format = eps, data_format
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format == "channels_first" and x.ndim == 4:  # stand-alone NCHW use keeps the reference contract
+            y = ops.layer_norm(x.permute(0, 2, 3, 1).contiguous(), self.weight, self.bias, self.eps)
+            return y.permute(0, 3, 1, 2)
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+# ------------------------------------------------------------------------------------------------ PVTv2
+class OverlapPatchEmbed(nn.Module):
+    """cod.py:964-1004."""
+
+    def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.patch_size, self.stride = patch_size, stride
+        self.proj = nn.Conv2d(in_chans, embed_dim, patch_size, stride, patch_size // 2)
+        self.norm = LayerNorm(embed_dim, eps=1e-5)
+        self.apply(_init_weights)
+
+    def forward(self, x):
+        x = self.proj(x)
+        H, W = x.shape[-2:]
+        x = x.flatten(2).transpose(1, 2).contiguous()
+        return self.norm(x), H, W
+
+
+class Attention(nn.Module):
+    """cod.py:862-921."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        assert dim // num_heads == 64, "the gfx950 attention kernel is specialised for head_dim 64 (cod.py:1785)"
+        assert attn_drop == 0. and proj_drop == 0., "reference configs use zero dropout (cod.py:1787)"
+        self.dim, self.num_heads, self.sr_ratio = dim, num_heads, sr_ratio
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = LayerNorm(dim, eps=1e-5)
+        self.apply(_init_weights)
+
+    def forward(self, x, H, W):
+        q = self.q(x)
+        if self.sr_ratio > 1:  # k == s conv == patchify + GEMM, stays token-major
+            r = F.linear(_patchify(x, H, W, self.sr_ratio), self.sr.weight.flatten(1), self.sr.bias)
+            r = self.norm(r)
+        else:
+            r = x
+        o = ops.sra_attention(q, self.kv(r), self.num_heads, self.scale)
+        return self.proj(o)
+
+
+class DWConv(nn.Module):
+    """cod.py:1520-1531."""
+
+    def __init__(self, dim=768):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+    def forward(self, x, H, W):
+        y = self.dwconv(_tokens_to_nchw(x, H, W))
+        return y.permute(0, 2, 3, 1).reshape(x.shape)
+
+
+class Mlp(nn.Module):
+    """cod.py:824-859."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.apply(_init_weights)
+
+    def forward(self, x, H, W):
+        return self.fc2(F.gelu(self.dwconv(self.fc1(x), H, W)))
+
+
+class Block(nn.Module):
+    """cod.py:924-961."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=None, sr_ratio=1):
+        super().__init__()
+        eps = 1e-6  # pvt_v2_b2 passes partial(nn.LayerNorm, eps=1e-6) (cod.py:1786)
+        self.norm1 = LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, sr_ratio=sr_ratio)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.apply(_init_weights)
+
+    def forward(self, x, H, W):
+        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
+        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+
+
+# ------------------------------------------------------------------------------------------------ diffuser
+class convnext_Block(nn.Module):
+    """cod.py:1082-1117, operating on NHWC tokens [B, H, W, C]."""
+
+    def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+
+    def forward_nhwc(self, x):
+        y = self.dwconv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
+        if self.gamma is not None:
+            y = self.gamma.to(y.dtype) * y
+        return x + self.drop_path(y)
+
+    def forward(self, x):  # reference contract: NCHW in, NCHW out
+        return self.forward_nhwc(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+
+
+class ShapePropEncoder(nn.Module):
+    """cod.py:1119-1177: ConvNeXt-B trunk (NHWC inside) + 4 taps -> out_dim channels at stride 4 (NCHW out)."""
+
+    def __init__(self, in_channels, out_dim):
+        super().__init__()
+        dims, depths = [128, 256, 512, 1024], [3, 3, 27, 3]
+        self.dims = dims
+        self.downsample_layers = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(3, dims[0], kernel_size=4, stride=4), LayerNorm(dims[0], eps=1e-6, data_format="channels_first"))]
+            + [nn.Sequential(LayerNorm(dims[i], eps=1e-6, data_format="channels_first"),
+                             nn.Conv2d(dims[i], dims[i + 1], kernel_size=2, stride=2)) for i in range(3)])
+        rates = [x.item() for x in torch.linspace(0, 0.4, sum(depths))]  # cod.py:1140-1145
+        self.stages, cur = nn.ModuleList(), 0
+        for i in range(4):
+            self.stages.append(nn.Sequential(*[convnext_Block(dims[i], rates[cur + j], 1.0) for j in range(depths[i])]))
+            cur += depths[i]
+        self.convs = nn.ModuleList([nn.Conv2d(dims[i], out_dim, 1) for i in range(4)])
+        self.fusion_conv = nn.Conv2d(out_dim * 4, out_dim, 1)
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        outs = []
+        # stem: conv k4 s4 == patchify + GEMM
+        conv, norm = self.downsample_layers[0]
+        t = x.view(B, 3, H // 4, 4, W // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 4) * (W // 4), 48)
+        t = norm(F.linear(t, conv.weight.flatten(1), conv.bias))
+        h, w = H // 4, W // 4
+        for i in range(4):
+            if i > 0:
+                norm, conv = self.downsample_layers[i]
+                t = F.linear(_patchify(norm(t), h, w, 2), conv.weight.flatten(1), conv.bias)
+                h, w = h // 2, w // 2
+            t4 = t.view(B, h, w, -1)
+            for blk in self.stages[i]:
+                t4 = blk.forward_nhwc(t4)
+            t = t4.reshape(B, h * w, -1)
+            outs.append((t, h, w))
+        size = (outs[0][1], outs[0][2])
+        taps = []
+        for (t, h, w), conv in zip(outs, self.convs):  # 1x1 conv == GEMM on tokens, then bilinear to stride 4
+            y = F.linear(t, conv.weight.flatten(1), conv.bias)
+            y = _tokens_to_nchw(y, h, w)
+            taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
+        return self.fusion_conv(torch.cat(taps, dim=1))
+
+
+class ShapePropWeightRegressor(nn.Module):
+    """cod.py:1051-1060."""
+
+    def __init__(self, in_channels, latent_dim):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.reg = nn.Conv2d(in_channels, latent_dim * 49, kernel_size=1)
+
+    def forward(self, x):
+        return torch.sigmoid(self.reg(x))
+
+
+class MessagePassing(nn.Module):
+    """cod.py:1180-1208 (random-walk normalisation branch)."""
+
+    def __init__(self, latent_dim, img_size=384, k=7, max_step=4, sym_norm=False):
+        super().__init__()
+        assert not sym_norm, "the reference's sym_norm branch references undefined attributes (cod.py:1194-1198)"
+        self.k, self.size, self.max_step, self.img_size = k, k * k, max_step, img_size
+        self.conv = nn.Conv2d(latent_dim, 3, 1)
+
+    def forward(self, input, weight):
+        n, c, h, w = input.shape
+        wgt = weight.view(n, weight.shape[1] // self.size, self.size, h * w)
+        wgt = wgt / (wgt.sum(2, keepdim=True) + 1e-5)
+        x = input
+        for _ in range(max(h, w) if self.max_step < 0 else self.max_step):
+            x = (F.unfold(x, self.k, padding=self.k // 2).view(n, c, self.size, h * w) * wgt).sum(2).view(n, c, h, w)
+        x = self.conv(x)
+        return F.interpolate(x, size=(self.img_size, self.img_size), mode="bilinear", align_corners=False)
+
+
+def fft_highpass(x: torch.Tensor, rate: float) -> torch.Tensor:
+    """cod.py:1256-1271 on the tensor's own device (rocFFT); no gradient path (input has none)."""
+    w, h = x.shape[-2:]
+    line = int((w * h * rate) ** .5 // 2)
+    x = x.float()
+    f = torch.fft.fftshift(torch.fft.fft2(x, norm="forward"), dim=(-2, -1))
+    f[..., w // 2 - line:w // 2 + line, h // 2 - line:h // 2 + line] = 0
+    return torch.fft.ifft2(torch.fft.ifftshift(f, dim=(-2, -1)), norm="forward").real.abs()
+
+
+class prompt_encoder(nn.Module):
+    """cod.py:1228-1306."""
+
+    def __init__(self, latent_dim, embed_dim, depth, fusion=False):
+        super().__init__()
+        self.embed_dim, self.depth = embed_dim, depth
+        self.propagation_weight_regressor = ShapePropWeightRegressor(3, latent_dim)
+        self.encoder1 = nn.Conv2d(1, latent_dim, 1)
+        self.encoder2 = ShapePropEncoder(3, 24)
+        self.adaptor = nn.Conv2d(6, 3, 1)  # constructed, never called (cod.py:1251)
+        self.message_passing = MessagePassing(latent_dim, img_size=384, sym_norm=False)
+        self.freq_nums = 0.3
+
+    def fft(self, x, rate):
+        return fft_highpass(x, rate)
+
+    def forward(self, image, cues, cross=False):
+        Hh = 12
+        with torch.autocast("cuda", enabled=False):
+            image32, cues32 = image.float(), cues.float()
+            x = self.fft(image32, self.freq_nums)
+            weights = self.propagation_weight_regressor(F.interpolate(x, size=[Hh, Hh]))
+            e1 = F.interpolate(self.encoder1(cues32), size=(Hh, Hh), mode="bilinear", align_corners=False)
+            self.message_passing.img_size = image.shape[-1]  # the reference pins 384 (cod.py:1252)
+            e2 = self.message_passing(e1, weights)
+            fused = e2 + image32
+        return x, self.encoder2(fused)
+
+
+class ShapePropDecoder(nn.Module):
+    """cod.py:1210-1226."""
+
+    def __init__(self, out_dim, latent_dim):
+        super().__init__()
+        self.decoder = nn.Sequential(nn.Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
+                                     nn.Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
+                                     nn.Conv2d(latent_dim, out_dim, 3, 1, 1))
+
+    def forward(self, embedding):
+        return self.decoder(embedding)
+
+
+class prompt_decoder(nn.Module):
+    """cod.py:1308-1323."""
+
+    def __init__(self, latent_dim, embed_dim, depth, fusion=False):
+        super().__init__()
+        self.depth = depth
+        self.decoder = nn.Sequential(*[ShapePropDecoder(embed_dim, 24) for _ in range(depth)])
+
+    def forward(self, embedding, cross=False):
+        return [self.decoder[i](embedding) for i in range(self.depth)]
+
+
+class PyramidVisionTransformerImpr(nn.Module):
+    """cod.py:1340-1517."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dims=[64, 128, 256, 512],
+                 num_heads=[1, 2, 4, 8], mlp_ratios=[4, 4, 4, 4], qkv_bias=False, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_layer=None, depths=[3, 4, 6, 3], sr_ratios=[8, 4, 2, 1]):
+        super().__init__()
+        self.num_classes, self.depths = num_classes, depths
+        chans = [in_chans] + list(embed_dims[:3])
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        cur = 0
+        for i in range(4):
+            setattr(self, f"patch_embed{i + 1}", OverlapPatchEmbed(img_size=img_size // (1 if i == 0 else 2 ** (i + 1)),
+                                                                   patch_size=7 if i == 0 else 3, stride=4 if i == 0 else 2,
+                                                                   in_chans=chans[i], embed_dim=embed_dims[i]))
+            setattr(self, f"block{i + 1}", nn.ModuleList([
+                Block(dim=embed_dims[i], num_heads=num_heads[i], mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias,
+                      qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[cur + j],
+                      sr_ratio=sr_ratios[i]) for j in range(depths[i])]))
+            setattr(self, f"norm{i + 1}", LayerNorm(embed_dims[i], eps=1e-6))
+            cur += depths[i]
+        self.latent_dim = LATENT
+        self.prompt_encoder = prompt_encoder(self.latent_dim, embed_dims, depths, True)
+        self.prompt_decoder = nn.Sequential(*[prompt_decoder(self.latent_dim, embed_dims[i], depths[i], True) for i in range(4)])
+        self.apply(_init_weights)
+        self.batch = 0
+
+    def forward_features(self, x, depth):
+        self.batch += 1
+        B = x.shape[0]
+        image = x
+        embedding1, embedding3 = self.prompt_encoder(image, depth)
+        outs = []
+        for i in range(4):
+            x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
+            prompts = self.prompt_decoder[i](embedding3)
+            for j, blk in enumerate(getattr(self, f"block{i + 1}")):
+                p = F.interpolate(prompts[j], size=(H, W), mode="bilinear", align_corners=False)
+                x = blk(x + p.flatten(2).transpose(1, 2), H, W)
+            x = getattr(self, f"norm{i + 1}")(x)
+            x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            outs.append(x)
+        return embedding1, outs
+
+    def forward(self, x, depth):
+        return self.forward_features(x, depth)
+
+
+class pvt_v2_b2(PyramidVisionTransformerImpr):
+    """cod.py:1781-1787."""
+
+    def __init__(self, **kwargs):
+        super().__init__(patch_size=4, embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8], mlp_ratios=[8, 8, 4, 4],
+                         qkv_bias=True, depths=[3, 4, 6, 3], sr_ratios=[8, 4, 2, 1], drop_rate=0.0,
+                         drop_path_rate=kwargs.get("drop_path_rate", 0.1))
+
+
+# ------------------------------------------------------------------------------------------------ Hitnet decoder
+class BasicConv2d(nn.Module):
+    """cod.py:355-368 (the ReLU is constructed but never applied)."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, dilation, bias=False)
+        self.bn = nn.BatchNorm2d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class CALayer(nn.Module):
+    """cod.py:415-431."""
+
+    def __init__(self, channel, reduction=16, bias=False):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1, bias=bias), nn.ReLU(inplace=True),
+                                     nn.Conv2d(channel // reduction, channel, 1, bias=bias), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.conv_du(self.avg_pool(x))
+
+
+class CAB(nn.Module):
+    """cod.py:436-451."""
+
+    def __init__(self, n_feat, kernel_size, reduction, bias, act):
+        super().__init__()
+        pad = kernel_size // 2
+        self.CA = CALayer(n_feat, reduction, bias=bias)
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias), act,
+                                  nn.Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias))
+
+    def forward(self, x):
+        return self.CA(self.body(x)) + x
+
+
+class SAM(nn.Module):
+    """cod.py:454-506."""
+
+    def __init__(self, ch_in=32, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(nn.Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(ch_in // reduction, ch_in, bias=False), nn.Sigmoid())
+        self.fc_wight = nn.Sequential(nn.Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
+                                      nn.Linear(ch_in // reduction, 1, bias=False), nn.Sigmoid())
+
+    def _gate(self, x):
+        y = x.mean((2, 3))
+        return x * self.fc(y)[:, :, None, None] * self.fc_wight(y)[:, :, None, None]
+
+    def forward(self, x_h, x_l):
+        return self._gate(x_h) + self._gate(x_l)
+
+
+class _ChannelAttention(nn.Module):  # cod.py:371-387; constructed (cod.py:703), never called
+    def __init__(self, in_planes):
+        super().__init__()
+        self.fc1 = nn.Conv2d(in_planes, in_planes // 16, 1, bias=False)
+        self.fc2 = nn.Conv2d(in_planes // 16, in_planes, 1, bias=False)
+
+
+class _SpatialAttention(nn.Module):  # cod.py:390-405; constructed (cod.py:704), never called
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(2, 1, 7, padding=3, bias=False)
+
+
+def _up(x, scale, align):
+    return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align)
+
+
+class Hitnet(nn.Module):
+    """cod.py:685-807."""
+
+    def __init__(self, channel=32, n_feat=32, scale_unetfeats=32, kernel_size=3, reduction=4, bias=False, act=None,
+                 drop_path_rate=0.1):
+        super().__init__()
+        act = act if act is not None else nn.PReLU()  # ONE shared instance (default argument at cod.py:686)
+        self.backbone = pvt_v2_b2(drop_path_rate=drop_path_rate)
+        if drop_path_rate == 0.0:
+            for m in self.backbone.modules():
+                if isinstance(m, DropPath):
+                    m.drop_prob = 0.0
+        self.Translayer2_0 = BasicConv2d(64, channel, 1)
+        self.Translayer2_1 = BasicConv2d(128, channel, 1)
+        self.Translayer3_1 = BasicConv2d(320, channel, 1)
+        self.Translayer4_1 = BasicConv2d(512, channel, 1)
+        self.ca = _ChannelAttention(64)
+        self.sa = _SpatialAttention()
+        self.SAM = SAM()
+        self.out_SAM = nn.Conv2d(channel, 1, 1)
+        self.out_CFM = nn.Conv2d(channel, 1, 1)
+        mk = lambda ch: nn.Sequential(*[CAB(ch, kernel_size, reduction, bias=bias, act=act) for _ in range(2)])
+        self.decoder_level4 = mk(n_feat)
+        self.decoder_level3 = mk(n_feat + scale_unetfeats)
+        self.decoder_level2 = mk(n_feat + scale_unetfeats * 2)
+        self.conv4 = BasicConv2d(3 * channel, channel, 3, padding=1)
+        self.decoder_level1 = mk(64)
+        self.compress_out = BasicConv2d(2 * channel, channel, kernel_size=8, stride=4, padding=2)
+        self.compress_out2 = BasicConv2d(2 * channel, channel, kernel_size=1)
+
+    def forward(self, x, pred_normal):
+        embedding1, (x1, x2, x3, x4) = self.backbone(x, pred_normal)
+        cim = self.decoder_level1(x1)
+        x2_t, x3_t, x4_t = self.Translayer2_1(x2), self.Translayer3_1(x3), self.Translayer4_1(x4)
+        stage_loss, cfm = [], None
+        for it in range(4):
+            if cfm is not None:
+                x4_t = self.compress_out(torch.cat((_up(x4_t, 4, True), cfm), 1))
+            x4f = self.decoder_level4(x4_t)
+            x3f = self.decoder_level3(torch.cat((x3_t, _up(x4f, 2, True)), 1))
+            if it > 0:
+                x2_t = self.compress_out2(torch.cat((x2_t, cfm), 1))
+            x2f = self.decoder_level2(torch.cat((x2_t, _up(x3f, 2, True)), 1))
+            cfm = self.conv4(x2f)
+            stage_loss.append(_up(self.out_CFM(cfm).float(), 8, False))
+        T2 = _up(self.Translayer2_0(cim), 0.5, True)
+        pred2 = _up(self.out_SAM(self.SAM(cfm, T2)).float(), 8, False)
+        return embedding1, stage_loss, pred2
+
+
+# ------------------------------------------------------------------------------------------------ losses / top level
+def cal_loss(preds, gts):
+    """cod.py:76-85."""
+    weit = 1 + 5 * torch.abs(F.avg_pool2d(gts, kernel_size=31, stride=1, padding=15) - gts)
+    wbce = F.binary_cross_entropy_with_logits(preds, gts, reduction="none")
+    wbce = (weit * wbce).sum(dim=(2, 3)) / weit.sum(dim=(2, 3))
+    p = torch.sigmoid(preds)
+    inter = ((p * gts) * weit).sum(dim=(2, 3))
+    union = ((p + gts) * weit).sum(dim=(2, 3))
+    return (wbce + 1 - (inter + 1) / (union - inter + 1)).mean()
+
+
+def ssim_value(x, y):
+    """cod.py:316-351 (value only; it has no gradient path to any parameter)."""
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    x, y = F.pad(x, (1, 1, 1, 1), mode="reflect"), F.pad(y, (1, 1, 1, 1), mode="reflect")
+    mu_x, mu_y = F.avg_pool2d(x, 3, 1), F.avg_pool2d(y, 3, 1)
+    sx = F.avg_pool2d(x * x, 3, 1) - mu_x ** 2
+    sy = F.avg_pool2d(y * y, 3, 1) - mu_y ** 2
+    sxy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + C1) * (2 * sxy + C2)
+    d = (mu_x ** 2 + mu_y ** 2 + C1) * (sx + sy + C2)
+    return torch.clamp((1 - n / d) / 2, 0, 1).mean(1, True).mean()
+
+
+def _stack(t):
+    return torch.stack(list(t), dim=0) if isinstance(t, (tuple, list)) else t
+
+
+class cod(nn.Module):
+    """cod.py:36-224: ``forward(raw, input, label, depth, mode)`` with mode in {'loss', 'predict'}.
+
+    Extra keyword arguments (ignored by the reference, cod.py:38-46) are accepted and ignored.
+    ``compute_dtype``: torch.float32 = exact-fp32 kernels (parity mode); torch.bfloat16 = bf16 MFMA
+    kernels + library GEMM/conv under bf16 autocast with fp32 master weights (throughput mode)."""
+
+    def __init__(self, win_size=None, filter_ratio=None, using_depth=None, using_sam=None, finetune=None,
+                 binary_thresh=None, pretrain_sam=None, head=None, img_size: int = 384,
+                 compute_dtype: torch.dtype = torch.float32, drop_path_rate: float = 0.1):
+        super().__init__()
+        self.hitnet = Hitnet(drop_path_rate=drop_path_rate)
+        self.batch = 0
+        self.compute_dtype = compute_dtype
+
+    def _run(self, input, depth):
+        if self.compute_dtype == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.hitnet(input, depth)
+        return self.hitnet(input, depth)
+
+    def forward(self, raw, input, label, depth, mode="loss"):
+        input, label, depth = _stack(input), _stack(label), _stack(depth)
+        if not input.is_cuda:
+            raise RuntimeError("dgtd.nn.cod runs on the MI355X HIP device only; the CPU restatement is oracle/cod_cpu.py")
+        embedding1, P1, P2 = self._run(input, depth)
+        if mode == "loss":
+            label = label.float()
+            losses = [cal_loss(p, label) for p in P1]
+            loss = cal_loss(P2, label)
+            for it in range(len(P1)):
+                loss = loss + (0.2 * it) * losses[it]
+            with torch.no_grad():
+                e = (embedding1 - embedding1.min()) / (embedding1.max() - embedding1.min() + 1e-8)
+                loss3 = ssim_value(e, input.float())
+            return {"loss": loss + loss3}
+        if mode == "predict":  # cod.py:152-153 + :219 (the PNG dumps of cod.py:156-217 are dropped)
+            out = F.interpolate(P1[-1] + P2, size=label.shape[-2:], mode="bilinear", align_corners=False)
+            return out.sigmoid(), label
+        raise NotImplementedError(f"Unsupported mode {mode}")

@@ -1,0 +1,127 @@
+"""GPU: the HIP-backed modules against the oracle (oracle/cod_cpu.py) and the committed goldens.
+Tolerances: BASELINE.json north_star — <= 1e-3 fp32 on the logit map, label indices identical
+(outside a reported |logit| < 1e-3 band)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cod_cpu, filler
+from oracle.make_golden import ATTN_CASES, BB, GOLDEN_DIR, tensor
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dgtd():
+    import dgtd as m
+    m._lib.load()
+    return m
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLDEN_DIR, "modules.npz"))
+
+
+@pytest.mark.parametrize("case", ATTN_CASES[:4], ids=[c[0] for c in ATTN_CASES[:4]])
+def test_attention_module_vs_golden(dgtd, G, case):
+    name, dim, heads, sr, hw, B = case
+    m = dgtd.nn.Attention(dim, num_heads=heads, qkv_bias=True, sr_ratio=sr).eval()
+    stage = {64: 1, 128: 2, 320: 3, 512: 4}[dim]
+    filler.fill_module(m, BB + f"block{stage}.0.attn.")
+    m = m.cuda()
+    with torch.no_grad():
+        y = m(tensor(name, (B, hw * hw, dim)).cuda(), hw, hw)
+    np.testing.assert_allclose(y.cpu().numpy(), G[name], rtol=1e-4, atol=1e-4)
+
+
+def test_block_and_patch_embed_vs_golden(dgtd, G):
+    m = dgtd.nn.Block(dim=128, num_heads=2, mlp_ratio=8, qkv_bias=True, sr_ratio=4).eval()
+    filler.fill_module(m, BB + "block2.1.")
+    with torch.no_grad():
+        y = m.cuda()(tensor("block2", (2, 256, 128)).cuda(), 16, 16)
+    np.testing.assert_allclose(y.cpu().numpy(), G["block2"], rtol=1e-4, atol=1e-4)
+    m = dgtd.nn.OverlapPatchEmbed(img_size=64, patch_size=7, stride=4, in_chans=3, embed_dim=64).eval()
+    filler.fill_module(m, BB + "patch_embed1.")
+    with torch.no_grad():
+        y, H, W = m.cuda()(tensor("patch_embed1", (2, 3, 64, 64)).cuda())
+    assert (H, W) == (16, 16)
+    np.testing.assert_allclose(y.cpu().numpy(), G["patch_embed1"], rtol=1e-4, atol=1e-4)
+    m = dgtd.nn.convnext_Block(dim=128, drop_path=0.0, layer_scale_init_value=1.0).eval()
+    filler.fill_module(m, BB + "prompt_encoder.encoder2.stages.0.1.")
+    with torch.no_grad():
+        y = m.cuda()(tensor("convnext128", (2, 128, 16, 16)).cuda())
+    np.testing.assert_allclose(y.cpu().numpy(), G["convnext128"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def pair64(dgtd):
+    g = np.load(os.path.join(GOLDEN_DIR, "model64.npz"))
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    filler.fill_module(net)
+    return g, net.cuda()
+
+
+def test_whole_model_eval_logits_and_labels(pair64):
+    g, net = pair64
+    net.eval()
+    x, d, l = (torch.from_numpy(g[k]).cuda() for k in ("input", "depth", "label"))
+    with torch.no_grad():
+        x_hp, P1, P2 = net.hitnet(x, d)
+        loss = net(None, list(x), list(l), list(d), mode="loss")["loss"]
+        prob, _ = net(None, x, l, d, mode="predict")
+    P1 = torch.stack(P1).cpu().numpy()
+    P2 = P2.cpu().numpy()
+    assert np.abs(P1 - g["eval.P1"]).max() <= LOGIT_TOL
+    assert np.abs(P2 - g["eval.P2"]).max() <= LOGIT_TOL
+    logit, ref = P1[-1] + P2, g["eval.P1"][-1] + g["eval.P2"]
+    assert np.abs(logit - ref).max() <= LOGIT_TOL
+    band = np.abs(ref) < LOGIT_TOL
+    assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])
+    assert np.array_equal((prob.cpu().numpy() > 0.5)[~band], (ref > 0)[~band])
+    assert abs(loss.item() - float(g["eval.loss"])) <= LOGIT_TOL
+    f = x_hp.double().flatten().cpu()
+    np.testing.assert_allclose(f[::int(g["eval.x_hp.step"])].float().numpy(), g["eval.x_hp.samples"], rtol=1e-4, atol=1e-5)
+
+
+def test_whole_model_train_loss_and_grads(pair64):
+    g, net = pair64
+    filler.fill_module(net)
+    net.train()
+    x, d, l = (torch.from_numpy(g[k]).cuda() for k in ("input", "depth", "label"))
+    net.zero_grad(set_to_none=True)
+    loss = net(None, x, l, d, mode="loss")["loss"]
+    assert abs(loss.item() - float(g["train.loss"])) <= LOGIT_TOL
+    loss.backward()
+    want = dict(zip(g["train.grad_names"].tolist(), g["train.grad_norms"].tolist()))
+    bad = []
+    for k, p in net.named_parameters():
+        if want[k] < 0:
+            assert p.grad is None, k
+            continue
+        got = p.grad.double().norm().item()
+        if abs(got - want[k]) > 2e-3 * want[k] + 1e-6:
+            bad.append((k, got, want[k]))
+    assert not bad, bad[:10]
+    bn = torch.cat([v.flatten() for k, v in net.state_dict().items() if "running_" in k]).cpu().numpy()
+    np.testing.assert_allclose(bn, g["train.bn_values"], rtol=1e-3, atol=1e-4)
+    filler.fill_module(net)
+
+
+def test_bf16_mode_close_to_oracle(dgtd):
+    """Throughput mode (bf16 MFMA kernels + bf16 GEMMs): logits stay close, labels agree away from 0."""
+    g = np.load(os.path.join(GOLDEN_DIR, "model64.npz"))
+    net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+    filler.fill_module(net)
+    net = net.cuda().eval()
+    x, d = (torch.from_numpy(g[k]).cuda() for k in ("input", "depth"))
+    with torch.no_grad():
+        _, P1, P2 = net.hitnet(x, d) if False else net._run(x, d)
+    logit = (P1[-1] + P2).float().cpu().numpy()
+    ref = g["eval.P1"][-1] + g["eval.P2"]
+    assert np.abs(logit - ref).max() < 0.1
+    band = np.abs(ref) < 0.1
+    assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])

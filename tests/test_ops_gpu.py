@@ -1,0 +1,103 @@
+"""GPU: every HIP op through the C ABI against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dgtd():
+    import dgtd as m
+    m._lib.load()
+    return m
+
+
+def _rand(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to("cuda").to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("C", [64, 128, 320, 512, 256, 1024])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(dgtd, C, dtype):
+    rows = 777  # ragged vs rows-per-block
+    x = _rand(rows, C, seed=C, dtype=dtype)
+    w = (1 + 0.1 * _rand(C, seed=1)).requires_grad_()
+    b = (0.1 * _rand(C, seed=2)).requires_grad_()
+    dy = _rand(rows, C, seed=3, dtype=dtype)
+    xr = x.float().requires_grad_()
+    ref = F.layer_norm(xr, (C,), w, b, 1e-6)
+    gx, gw, gb = torch.autograd.grad(ref, (xr, w, b), dy.float())
+    xs = x.clone().requires_grad_()
+    y = dgtd.ops.layer_norm(xs, w, b, 1e-6)
+    hx, hw, hb = torch.autograd.grad(y, (xs, w, b), dy)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert y.dtype == dtype
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
+    gtol = 2e-4 if dtype == torch.float32 else 5e-2
+    torch.testing.assert_close(hw, gw, atol=gtol * math.sqrt(rows), rtol=gtol)
+    torch.testing.assert_close(hb, gb, atol=gtol * math.sqrt(rows), rtol=gtol)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, kv, heads, scale):
+    B, N, C = q.shape
+    d = C // heads
+    qh = q.view(B, N, heads, d).transpose(1, 2)
+    kvh = kv.view(B, -1, 2, heads, d).permute(2, 0, 3, 1, 4)
+    p = torch.softmax((qh @ kvh[0].transpose(-2, -1)) * scale, dim=-1)
+    return (p @ kvh[1]).transpose(1, 2).reshape(B, N, C)
+
+
+# (B, N, Nkv, heads): the four PVT stages at S=256 and S=512, S=384's N_kv=144, ragged/tiny cases,
+# and N_kv=1024 (S=1024) which exercises the multi-chunk online softmax and the key-slice loop of the backward.
+ATTN_SHAPES = [(2, 4096, 64, 1), (2, 1024, 64, 2), (2, 256, 64, 5), (2, 64, 64, 8),
+               (1, 16384, 256, 1), (1, 4096, 256, 2), (2, 1024, 256, 5), (2, 256, 256, 8),
+               (1, 2304, 144, 2), (2, 4, 4, 8), (1, 1, 1, 8), (3, 100, 37, 2), (1, 2048, 1024, 2)]
+
+
+@pytest.mark.parametrize("shape", ATTN_SHAPES, ids=[str(s) for s in ATTN_SHAPES])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sra_attention_fwd_bwd(dgtd, shape, dtype):
+    B, N, Nkv, heads = shape
+    C = heads * 64
+    q = _rand(B, N, C, seed=1, dtype=dtype)
+    kv = _rand(B, Nkv, 2 * C, seed=2, dtype=dtype)
+    do = _rand(B, N, C, seed=3, dtype=dtype)
+    scale = 64 ** -0.5
+    qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+    ref = _attn_ref(qr, kvr, heads, scale)
+    gq, gkv = torch.autograd.grad(ref, (qr, kvr), do.float())
+    qs, kvs = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    out = dgtd.ops.sra_attention(qs, kvs, heads, scale)
+    hq, hkv = torch.autograd.grad(out, (qs, kvs), do)
+    if dtype == torch.float32:
+        # exact-fp32 MFMA: the 1e-3 logit budget of BASELINE.json needs op error well below it
+        torch.testing.assert_close(out, ref, atol=2e-5, rtol=2e-5)
+        torch.testing.assert_close(hq, gq, atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(hkv, gkv, atol=2e-4 * math.sqrt(N / 64), rtol=1e-3)
+    else:
+        torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=3e-2)
+        torch.testing.assert_close(hq.float(), gq, atol=5e-2, rtol=5e-2)
+        rel = (hkv.float() - gkv).norm() / gkv.norm()
+        assert rel < 2e-2, rel
+
+
+def test_attention_spiked_scores_online_softmax(dgtd):
+    """Force the running-max rescale across K/V chunks (guide §5.4 rule 26): one key in the LAST chunk
+    dominates one query row."""
+    B, N, Nkv, heads = 1, 64, 1024, 1
+    q = _rand(B, N, 64, seed=5)
+    kv = _rand(B, Nkv, 128, seed=6)
+    kv[0, 1000, :64] = q[0, 7] * 4.0
+    ref = _attn_ref(q, kv, heads, 0.125)
+    out = dgtd.ops.sra_attention(q, kv, heads, 0.125)
+    torch.testing.assert_close(out, ref, atol=2e-5, rtol=2e-5)
+    out16 = dgtd.ops.sra_attention(q.bfloat16(), kv.bfloat16(), heads, 0.125)
+    ref16 = _attn_ref(q.bfloat16().float(), kv.bfloat16().float(), heads, 0.125)
+    torch.testing.assert_close(out16.float(), ref16, atol=3e-2, rtol=3e-2)
