@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py — training-step throughput of the HIP-backed `cod` model on synthetic 512x512 RGB-D batches.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = forward + loss + backward + gradient all-reduce (RCCL, N>1) + AdamW update, batch 8 per GPU
+(BASELINE.json configs[1]: config/sod.yml model, 512x512, batch 8, bf16).  Rank 0 prints ONE JSON line.
+Inputs are resident in HBM before the timed region.  After the timed region a separate instrumented pass times
+every hand-written kernel with HIP events on its launch stream (roofline), and rank 0 at N=1 times the CPU
+oracle on a bounded sample (cpu_baseline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"hbm": (8000.0, "GB/s"), "mfma_bf16": (2500.0, "TFLOP/s"), "mfma_f32": (157.3, "TFLOP/s")}  # MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+    from oracle import cod_cpu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    net = cod_cpu.cod(size).train()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 3, size, size, generator=g)
+    d = torch.rand(B, 1, size, size, generator=g)
+    l = (torch.rand(B, 1, size, size, generator=g) > 0.5).float()
+    t0 = time.perf_counter()
+    loss = net(None, x, l, d, mode="loss")["loss"]
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 step fwd+loss+bwd of oracle/cod_cpu.py, {size}x{size}, batch {B}, fp32, {cores} torch threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import dgtd
+    rank, local, world = dgtd.dist.init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)
+    net = dgtd.nn.cod(compute_dtype=dtype).to(dev).train()   # random init of the reference architecture, DropPath active
+    dgtd.dist.broadcast_parameters(net)
+    reducer = dgtd.dist.GradReducer(net)
+    opt = dgtd.runner.build_optimizer(net)
+    data = dgtd.runner.SyntheticRGBD(args.size, args.batch, rank=rank, device=dev)
+    batches = [data.batch_at(i) for i in range(2)]  # resident in HBM before timing
+
+    def step(i):
+        b = batches[i % len(batches)]
+        reducer.zero_grad()
+        loss = net(b["raw"], b["input"], b["label"], b["depth"], mode="loss")["loss"]
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    # ---- instrumented pass: per-kernel HIP-event timing (not part of `value`)
+    roofline, kernels = None, []
+    if rank == 0 and args.profile_steps > 0:
+        dgtd._lib.PROFILER = dgtd._lib.Profiler()
+        for i in range(args.profile_steps):
+            step(i)
+        summ = dgtd._lib.PROFILER.summary()
+        dgtd._lib.PROFILER = None
+        for key, e in summ.items():
+            if e["amount"] <= 0 or e["ms"] <= 0:
+                continue
+            mfma = e["bound"] == "mfma"
+            peak, unit = PEAK[("mfma_bf16" if dtype == torch.bfloat16 else "mfma_f32") if mfma else "hbm"]
+            per_s = e["amount"] / (e["ms"] * 1e-3)
+            achieved = per_s / 1e12 if mfma else per_s / 1e9
+            kernels.append({"kernel": key, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
+                            "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": e["calls"] / args.profile_steps,
+                            "avg_us": round(1e3 * e["ms"] / e["calls"], 2), "ms_per_step": round(e["ms"] / args.profile_steps, 3),
+                            "traffic": None})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        if kernels:
+            roofline = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            roofline["kernel"] = kernels[0]["kernel"]
+            roofline["avg_us"] = kernels[0]["avg_us"]
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        imgs = args.steps * args.batch * world
+        out = {
+            "metric": "training images/sec (512x512 RGB-D, bs=8 per GPU; fwd+loss+bwd+allreduce+AdamW)",
+            "value": round(imgs / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "per_gpu": round(imgs / dt / world, 3), "target_per_gpu": 40.0,
+            "config": {"workload": f"config/sod.yml model `cod` (PVTv2-b2 + ConvNeXt-B texture diffuser + Hitnet decoder), "
+                                   f"{args.size}x{args.size} RGB+depth, batch {args.batch}/GPU, random init, DropPath active",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       "tflops_sustained": round(imgs / dt * 786.7e9 * (args.size / 512) ** 2 / 1e12, 2)},
+            "roofline": roofline, "kernels": kernels[:12],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

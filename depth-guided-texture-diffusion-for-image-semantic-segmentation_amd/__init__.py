@@ -9,5 +9,6 @@ from . import _lib  # noqa: F401
 from . import ops  # noqa: F401
 from . import nn  # noqa: F401
 from . import dist  # noqa: F401
+from . import runner  # noqa: F401
 
-__all__ = ["_lib", "ops", "nn", "dist"]
+__all__ = ["_lib", "ops", "nn", "dist", "runner"]

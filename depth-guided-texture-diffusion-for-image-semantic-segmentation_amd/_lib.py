@@ -71,9 +71,38 @@ def check_cuda(*ts: torch.Tensor) -> None:
             raise DgtdError("dgtd ops need contiguous tensors")
 
 
-def call(name: str, *args):
+class Profiler:
+    """HIP-event timing of every C-ABI launch on the stream it is launched on (bench.py's roofline leg).
+    ``algo`` = (bound, amount): algorithmic HBM bytes or MFMA flops of that launch."""
+
+    def __init__(self):
+        self.records = []  # (key, start_event, stop_event, bound, amount)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, a, b, bound, amount in self.records:
+            e = out.setdefault(key, {"calls": 0, "ms": 0.0, "amount": 0.0, "bound": bound})
+            e["calls"] += 1
+            e["ms"] += a.elapsed_time(b)
+            e["amount"] += amount
+        return out
+
+
+PROFILER = None
+
+
+def call(name: str, *args, algo=None, key=None):
     lib = load()
+    prof = PROFILER
+    if prof is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
     rc = getattr(lib, name)(*args)
+    if prof is not None:
+        b.record()
+        bound, amount = algo if algo is not None else ("hbm", 0.0)
+        prof.records.append((key or name, a, b, bound, float(amount)))
     if rc != 0:
         raise DgtdError(f"{name} failed (code {rc}): {lib.dgtd_last_error().decode()}")
 

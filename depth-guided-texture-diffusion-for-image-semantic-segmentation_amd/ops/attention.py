@@ -20,7 +20,8 @@ class _SraAttnFn(Function):
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
         L.call("dgtd_sra_attn_fwd", L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(lse), B, N, Nkv, heads, float(scale),
-               L.dtype_code(q), L.stream_ptr())
+               L.dtype_code(q), L.stream_ptr(), algo=("mfma", 4.0 * B * heads * N * Nkv * 64),
+               key=f"dgtd_sra_attn_fwd[N={N},Nkv={Nkv},h={heads}]")
         ctx.save_for_backward(q, kv, out, lse)
         ctx.heads, ctx.scale = heads, float(scale)
         return out
@@ -38,7 +39,8 @@ class _SraAttnFn(Function):
         dkv = torch.zeros(kv.shape, dtype=torch.float32, device=q.device)
         ws = torch.empty(L.load().dgtd_sra_attn_bwd_workspace(B, N, ctx.heads), dtype=torch.uint8, device=q.device)
         L.call("dgtd_sra_attn_bwd", L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(dq), L.ptr(dkv),
-               L.ptr(ws), B, N, Nkv, ctx.heads, ctx.scale, L.dtype_code(q), L.stream_ptr())
+               L.ptr(ws), B, N, Nkv, ctx.heads, ctx.scale, L.dtype_code(q), L.stream_ptr(),
+               algo=("mfma", 10.0 * B * ctx.heads * N * Nkv * 64), key=f"dgtd_sra_attn_bwd[N={N},Nkv={Nkv},h={ctx.heads}]")
         return dq, dkv.to(kv.dtype), None, None
 
 

@@ -20,7 +20,8 @@ class _LayerNormFn(Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         L.call("dgtd_layernorm_fwd", L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.ptr(mean), L.ptr(rstd),
-               rows, C, float(eps), L.dtype_code(x), L.stream_ptr())
+               rows, C, float(eps), L.dtype_code(x), L.stream_ptr(),
+               algo=("hbm", 2 * x.element_size() * rows * C))
         ctx.save_for_backward(x, w32, mean, rstd)
         return y
 
@@ -38,7 +39,8 @@ class _LayerNormFn(Function):
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = torch.empty(L.load().dgtd_layernorm_bwd_workspace(C), dtype=torch.uint8, device=x.device)
         L.call("dgtd_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(w32), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
-               L.ptr(dg), L.ptr(db), L.ptr(ws), rows, C, L.dtype_code(x), L.stream_ptr())
+               L.ptr(dg), L.ptr(db), L.ptr(ws), rows, C, L.dtype_code(x), L.stream_ptr(),
+               algo=("hbm", 3 * x.element_size() * rows * C))
         return dx, dg, db, None
 
 

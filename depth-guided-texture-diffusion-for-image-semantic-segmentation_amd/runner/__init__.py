@@ -1,0 +1,3 @@
+"""Minimal pieces of the training loop the reference delegates to nest/mmengine."""
+from .optim import build_optimizer, lr_mult_for  # noqa: F401
+from .data import SyntheticRGBD  # noqa: F401
