@@ -306,15 +306,15 @@ class prompt_encoder(nn.Module):
         return fft_highpass(x, rate)
 
     def forward(self, image, cues, cross=False):
-        Hh = 12
         with torch.autocast("cuda", enabled=False):
-            image32, cues32 = image.float(), cues.float()
+            image32 = image.float()
             x = self.fft(image32, self.freq_nums)
-            weights = self.propagation_weight_regressor(F.interpolate(x, size=[Hh, Hh]))
-            e1 = F.interpolate(self.encoder1(cues32), size=(Hh, Hh), mode="bilinear", align_corners=False)
-            self.message_passing.img_size = image.shape[-1]  # the reference pins 384 (cod.py:1252)
-            e2 = self.message_passing(e1, weights)
-            fused = e2 + image32
+            # one fused launch per (image, latent channel): regressor + depth embedding + 4 propagation steps
+            reg = self.propagation_weight_regressor.reg
+            x4 = ops.diffuser_state(x, cues, reg.weight, reg.bias, self.encoder1.weight, self.encoder1.bias)
+            # 1x1 conv 24->3, bilinear 12 -> S (the reference pins 384, cod.py:1252), + image: one HBM-bound pass
+            mp = self.message_passing.conv
+            fused = ops.diffuse_tail(x4, mp.weight, mp.bias, image32)
         return x, self.encoder2(fused)
 
 

@@ -59,6 +59,27 @@ int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void
                       const float* lse, void* dq, float* dkv_f32, void* workspace,
                       int B, int N, int Nkv, int heads, float scale, dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Texture diffuser front end (fp32) -------------------------------------------------------
+ * replaces twig/model/cod.py:1295-1298 (nearest 12x12 sample of the FFT high-pass image, 1x1 conv 3->1176,
+ * sigmoid; depth 1x1 conv 1->24 + bilinear to 12x12) and MessagePassing.forward cod.py:1193-1205
+ * (random-walk normalisation + 4 zero-padded 7x7 propagation steps).
+ * x_hp [B,3,S,S], depth [B,1,S,S]; reg_w [1176,3], reg_b [1176] (regressor channel = c*49 + ky*7 + kx);
+ * enc_w [24], enc_b [24]  ->  x4 [B,24,12,12].                                                   */
+int dgtd_diffuser_fwd(const float* x_hp, const float* depth, const float* reg_w, const float* reg_b,
+                      const float* enc_w, const float* enc_b, float* x4, int B, int S, dgtd_stream s);
+/* parameter gradients only (the inputs carry none); d_* must be ZEROED by the caller (atomics over batch). */
+int dgtd_diffuser_bwd(const float* x_hp, const float* depth, const float* reg_w, const float* reg_b,
+                      const float* enc_w, const float* enc_b, const float* g4, float* d_reg_w,
+                      float* d_reg_b, float* d_enc_w, float* d_enc_b, int B, int S, dgtd_stream s);
+/* out [B,3,S,S] = bilinear_{12->S, align_corners=False}(conv1x1(x4; cw [3,24], cb [3])) + image
+ * replaces cod.py:1206-1207 and the `+ image` of cod.py:1302.                                     */
+int dgtd_diffuse_tail_fwd(const float* x4, const float* cw, const float* cb, const float* image,
+                          float* out, int B, int S, dgtd_stream s);
+int64_t dgtd_diffuse_tail_bwd_workspace(int B);
+/* g4 [B,24,12,12] overwritten; d_cw [3,24], d_cb [3] ZEROED by the caller.                        */
+int dgtd_diffuse_tail_bwd(const float* gout, const float* x4, const float* cw, float* g4, float* d_cw,
+                          float* d_cb, void* workspace, int B, int S, dgtd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,32 @@ def test_attention_spiked_scores_online_softmax(dgtd):
     out16 = dgtd.ops.sra_attention(q.bfloat16(), kv.bfloat16(), heads, 0.125)
     ref16 = _attn_ref(q.bfloat16().float(), kv.bfloat16().float(), heads, 0.125)
     torch.testing.assert_close(out16.float(), ref16, atol=3e-2, rtol=3e-2)
+
+
+# ---------------------------------------------------------------------------------------------- texture diffuser
+@pytest.mark.parametrize("S", [64, 96, 512])
+def test_diffuser_front_end_vs_oracle(dgtd, S):
+    """diffuser_state + diffuse_tail against the oracle's PromptEncoder front end (cod.py:1295-1302), values and
+    parameter gradients.  S=96 exercises a non-integer nearest/bilinear scale (96/12 = 8 exact, 64/12 is not)."""
+    from oracle import cod_cpu, filler
+    B = 2
+    pe = cod_cpu.PromptEncoder(S)
+    pe.encoder2 = torch.nn.Identity()  # only the front end is under test
+    filler.fill_module(pe, "hitnet.backbone.prompt_encoder.")
+    g = torch.Generator().manual_seed(S)
+    image = torch.randn(B, 3, S, S, generator=g)
+    depth = torch.rand(B, 1, S, S, generator=g)
+    gout = torch.randn(B, 3, S, S, generator=g)
+    x_hp, fused = pe(image, depth)
+    names = ["propagation_weight_regressor.reg.weight", "propagation_weight_regressor.reg.bias", "encoder1.weight",
+             "encoder1.bias", "message_passing.conv.weight", "message_passing.conv.bias"]
+    params = dict(pe.named_parameters())
+    want = torch.autograd.grad(fused, [params[n] for n in names], gout)
+
+    dev = [params[n].detach().cuda().requires_grad_() for n in names]
+    x4 = dgtd.ops.diffuser_state(x_hp.cuda(), depth.cuda(), dev[0], dev[1], dev[2], dev[3])
+    out = dgtd.ops.diffuse_tail(x4, dev[4], dev[5], image.cuda())
+    torch.testing.assert_close(out.cpu(), fused.detach(), atol=2e-5, rtol=2e-5)
+    got = torch.autograd.grad(out, dev, gout.cuda())
+    for n, a, b in zip(names, got, want):
+        torch.testing.assert_close(a.cpu(), b, atol=2e-4 * max(1.0, b.abs().max().item()), rtol=2e-3, msg=lambda m, n=n: f"{n}: {m}")
