@@ -59,6 +59,9 @@ def cpu_baseline(size: int):
 
 def main():
     args = parse()
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run shows where it is stuck
+    t_start = time.perf_counter()
     import dgtd
     rank, local, world = dgtd.dist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -88,14 +91,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     for i in range(args.warmup):
+        tw = time.perf_counter()
         step(i)
+        torch.cuda.synchronize()
+        log(f"warmup step {i}: {time.perf_counter() - tw:.2f} s")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed {args.steps} steps: {dt:.2f} s")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -109,6 +120,7 @@ def main():
         for i in range(args.profile_steps):
             step(i)
         summ = dgtd._lib.PROFILER.summary()
+        log("instrumented pass done")
         dgtd._lib.PROFILER = None
         for key, e in summ.items():
             if e["amount"] <= 0 or e["ms"] <= 0:
@@ -144,7 +156,9 @@ def main():
             "roofline": roofline, "kernels": kernels[:12],
         }
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(args.size)
+        faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
