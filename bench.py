@@ -41,9 +41,13 @@ def parse():
 def cpu_baseline(size: int):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
     from oracle import cod_cpu
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))   # the GPU box grants a 16-core share per GPU; more threads only oversubscribe
     torch.set_num_threads(cores)
-    B = 2
+    B = 1
     net = cod_cpu.cod(size).train()
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 3, size, size, generator=g)
