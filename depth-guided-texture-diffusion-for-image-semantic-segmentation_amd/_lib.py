@@ -26,6 +26,8 @@ SIGNATURES = {
     "dgtd_sra_attn_fwd": (_i, [_vp, _vp, _vp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
     "dgtd_sra_attn_bwd_workspace": (_i64, [_i, _i, _i]),
     "dgtd_sra_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _fp, _vp, _fp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dgtd_dwconv_fwd": (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_dwconv_bwd_weight": (_i, [_vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_diffuser_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuser_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),

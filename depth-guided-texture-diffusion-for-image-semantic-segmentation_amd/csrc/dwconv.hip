@@ -1,0 +1,219 @@
+// dwconv.hip — depthwise KxK convolution (stride 1, "same" zero padding) on token-major / NHWC tensors.
+// Replaces  convnext_Block.dwconv  7x7 (twig/model/cod.py:1095,1106; 36 blocks)   and
+//           DWConv.dwconv 3x3 + bias, fused with the exact-erf GELU of Mlp (cod.py:1523-1531, :854-855; 16 blocks),
+// both of which the reference runs in NCHW behind two permute copies.
+//
+// HBM-bound.  Algorithmic bytes: fwd 2*e*B*H*W*C;  bwd-data 2*e*B*H*W*C;  bwd-weight 2*e*B*H*W*C (+K*K*C*4).
+// Mapping: channels are the contiguous dim, so lanes run along C (16 B per lane in fwd -> fully coalesced rows);
+// each thread produces a strip of TX consecutive x positions so the K taps along x are reused from registers;
+// the K-fold reuse along y is served by L1/L2 (neighbouring rows are computed by neighbouring workgroups).
+// bwd-data is the same kernel with the spatially flipped filter.  bwd-weight keeps a K*K x 2-channel accumulator per
+// lane, sums the four waves of a workgroup through LDS atomics and leaves with one fp32 global atomic per tap/channel.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// MODE 0: y = conv(x) + bias          MODE 1: y = gelu(conv(x) + bias)
+// MODE 2: y = aux * gelu'(conv(x) + bias)   (aux = upstream gradient; recomputes the pre-activation)
+template <typename T, int V> struct VecN { typedef T type __attribute__((ext_vector_type(V))); };
+
+template <typename T, int V, int K, int TX, int MODE>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, const T* __restrict__ aux,
+                                                         T* __restrict__ y, int B, int H, int W, int C) {
+  typedef typename VecN<T, V>::type VT;
+  constexpr int P = K / 2;
+  const int CV = C / V, XB = (W + TX - 1) / TX;
+  const int64_t total = (int64_t)B * H * XB * CV;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(gid % CV);
+    int64_t strip = gid / CV;
+    const int xb = (int)(strip % XB); strip /= XB;
+    const int yy0 = (int)(strip % H);
+    const int b = (int)(strip / H);
+    const int x0 = xb * TX, c0 = cv * V;
+    float acc[TX][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float bv = bias ? bias[c0 + j] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TX; ++t) acc[t][j] = bv;
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int yy = yy0 + ky - P;
+      if (yy < 0 || yy >= H) continue;
+      const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+      float in[TX + K - 1][V];
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) {
+        const int xx = x0 + i - P;
+        if (xx >= 0 && xx < W) {
+          VT v = *reinterpret_cast<const VT*>(row + (size_t)xx * C);
+#pragma unroll
+          for (int j = 0; j < V; ++j) in[i][j] = (float)v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) in[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        float wv[V];
+        const float* wp = wt + (size_t)(ky * K + kx) * C + c0;
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + j);
+          wv[j] = w4[0]; wv[j + 1] = w4[1]; wv[j + 2] = w4[2]; wv[j + 3] = w4[3];
+        }
+#pragma unroll
+        for (int t = 0; t < TX; ++t)
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[t][j] += in[t + kx][j] * wv[j];
+      }
+    }
+    T* orow = y + (((size_t)b * H + yy0) * W) * C + c0;
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+      const int xx = x0 + t;
+      if (xx < W) {
+        VT o;
+        if (MODE == 2) {
+          VT g = *reinterpret_cast<const VT*>(aux + (((size_t)b * H + yy0) * W + xx) * C + c0);
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = (T)((float)g[j] * gelu_grad_f(acc[t][j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = (T)(MODE == 1 ? gelu_f(acc[t][j]) : acc[t][j]);
+        }
+        *reinterpret_cast<VT*>(orow + (size_t)xx * C) = o;
+      }
+    }
+  }
+}
+
+// 2 channels per lane (one 4-byte bf16x2 / 8-byte float2 load); one wave = 128 channels of one strip.
+template <typename T> struct Pair;
+template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pair<bf16_t> { typedef bf16_t type __attribute__((ext_vector_type(2))); };
+
+template <typename T, int K, int TX>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
+                                                                float* __restrict__ dwt, float* __restrict__ db,
+                                                                int B, int H, int W, int C) {
+  typedef typename Pair<T>::type PT;
+  constexpr int P = K / 2, KK = K * K;
+  __shared__ float red[KK + 1][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * 128 + lane * 2;
+  const int XB = (W + TX - 1) / TX;
+  const int64_t nstrips = (int64_t)B * H * XB;
+  for (int i = tid; i < (KK + 1) * 128; i += 256) (&red[0][0])[i] = 0.f;
+  float acc[KK][2], accb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < KK; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < nstrips; s += (int64_t)gridDim.x * 4) {
+    int64_t r = s;
+    const int xb = (int)(r % XB); r /= XB;
+    const int yy0 = (int)(r % H);
+    const int b = (int)(r / H);
+    const int x0 = xb * TX;
+    float g[TX][2];
+    const T* grow = du + (((size_t)b * H + yy0) * W) * C + c0;
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+      if (x0 + t < W) {
+        PT v = *reinterpret_cast<const PT*>(grow + (size_t)(x0 + t) * C);
+        g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
+      } else { g[t][0] = 0.f; g[t][1] = 0.f; }
+      accb[0] += g[t][0]; accb[1] += g[t][1];
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int yy = yy0 + ky - P;
+      if (yy < 0 || yy >= H) continue;
+      const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+      float in[TX + K - 1][2];
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) {
+        const int xx = x0 + i - P;
+        if (xx >= 0 && xx < W) {
+          PT v = *reinterpret_cast<const PT*>(row + (size_t)xx * C);
+          in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
+        } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) {
+          acc[ky * K + kx][0] += g[t][0] * in[t + kx][0];
+          acc[ky * K + kx][1] += g[t][1] * in[t + kx][1];
+        }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < KK; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
+  atomicAdd(&red[KK][lane * 2], accb[0]); atomicAdd(&red[KK][lane * 2 + 1], accb[1]);
+  __syncthreads();
+  for (int i = tid; i < (KK + 1) * 128; i += 256) {
+    const int t = i >> 7, c = i & 127;
+    const float v = red[t][c];
+    if (t < KK) atomicAdd(&dwt[(size_t)t * C + blockIdx.y * 128 + c], v);
+    else if (db) atomicAdd(&db[blockIdx.y * 128 + c], v);
+  }
+}
+
+template <typename T, int V, int K, int TX>
+int fwd_launch(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C,
+               int mode, hipStream_t s) {
+  DGTD_REQUIRE(C % V == 0, "dwconv: C=%d must be a multiple of %d", C, V);
+  const int64_t total = (int64_t)B * H * cdiv(W, TX) * (C / V);
+  const int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+#define DW_LAUNCH(MODE) hipLaunchKernelGGL((dwconv_fwd_kernel<T, V, K, TX, MODE>), dim3(grid), dim3(256), 0, s, (const T*)x, wt, bias, (const T*)aux, (T*)y, B, H, W, C)
+  if (mode == 0) DW_LAUNCH(0); else if (mode == 1) DW_LAUNCH(1); else DW_LAUNCH(2);
+#undef DW_LAUNCH
+  DGTD_CHECK_LAUNCH("dwconv_fwd");
+  return 0;
+}
+
+template <typename T, int K, int TX>
+int bww_launch(const void* x, const void* du, float* dwt, float* db, int B, int H, int W, int C, hipStream_t s) {
+  DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
+  const int ncb = C / 128;
+  const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 4), 2048 / ncb));
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(256), 0, s, (const T*)x, (const T*)du, dwt, db, B, H, W, C);
+  DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y, int B, int H, int W,
+                               int C, int K, int mode, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_fwd: bad sizes");
+  DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
+  DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
+  hipStream_t st = (hipStream_t)s;
+  if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                     : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                    : fwd_launch<float, 4, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  DGTD_FAIL(2, "dwconv_fwd: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t, float* db, int B, int H, int W, int C, int K,
+                                      dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight: bad sizes");
+  DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight: K=%d (only 3 and 7 are on the path)", K);
+  hipStream_t st = (hipStream_t)s;
+  if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<bf16_t, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
+  if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<float, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
+  DGTD_FAIL(2, "dwconv_bwd_weight: bad dtype %d", (int)dt);
+}

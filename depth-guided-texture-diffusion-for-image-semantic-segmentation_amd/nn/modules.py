@@ -137,9 +137,9 @@ class DWConv(nn.Module):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
-    def forward(self, x, H, W):
-        y = self.dwconv(_tokens_to_nchw(x, H, W))
-        return y.permute(0, 2, 3, 1).reshape(x.shape)
+    def forward(self, x, H, W, gelu: bool = False):
+        B, N, Cc = x.shape
+        return ops.dwconv_nhwc(x.view(B, H, W, Cc), self.dwconv.weight, self.dwconv.bias, gelu).view(B, N, Cc)
 
 
 class Mlp(nn.Module):
@@ -155,7 +155,7 @@ class Mlp(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
-        return self.fc2(F.gelu(self.dwconv(self.fc1(x), H, W)))
+        return self.fc2(self.dwconv(self.fc1(x), H, W, gelu=True))  # dw3x3 + bias + exact GELU in one pass
 
 
 class Block(nn.Module):
@@ -191,7 +191,7 @@ class convnext_Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward_nhwc(self, x):
-        y = self.dwconv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        y = ops.dwconv_nhwc(x, self.dwconv.weight, self.dwconv.bias)
         y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
         if self.gamma is not None:
             y = self.gamma.to(y.dtype) * y

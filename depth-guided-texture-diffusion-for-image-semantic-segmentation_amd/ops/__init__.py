@@ -4,3 +4,4 @@ once_differentiable and returns one gradient per input."""
 from .layernorm import layer_norm  # noqa: F401
 from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401
+from .dwconv import dwconv_nhwc  # noqa: F401

@@ -59,6 +59,19 @@ int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void
                       const float* lse, void* dq, float* dkv_f32, void* workspace,
                       int B, int N, int Nkv, int heads, float scale, dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Depthwise KxK convolution, stride 1, "same" zero padding, NHWC / token-major ----------------
+ * replaces convnext_Block.dwconv 7x7 (twig/model/cod.py:1095,1106) and DWConv 3x3 + bias fused with Mlp's
+ * exact GELU (cod.py:1523-1531, :854-855).  x, y [B,H,W,C]; w_t fp32 [K*K, C] (= Conv2d weight [C,1,K,K]
+ * transposed so that tap rows are contiguous in C); bias fp32 [C] or NULL.  K in {3, 7}.
+ * mode 0: y = conv(x)+bias   mode 1: y = gelu(conv(x)+bias)   mode 2: y = aux * gelu'(conv(x)+bias)
+ * (mode 2 is the backward through the fused GELU: aux = upstream gradient, pre-activation recomputed).
+ * Backward w.r.t. x = mode 0 applied to the gradient with the spatially flipped filter.            */
+int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y,
+                    int B, int H, int W, int C, int K, int mode, dgtd_dtype dt, dgtd_stream s);
+/* dw_t fp32 [K*K, C] and db fp32 [C] (db may be NULL) must be ZEROED by the caller; C % 128 == 0.   */
+int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t, float* db,
+                           int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
+
 /* ---- Texture diffuser front end (fp32) -------------------------------------------------------
  * replaces twig/model/cod.py:1295-1298 (nearest 12x12 sample of the FFT high-pass image, 1x1 conv 3->1176,
  * sigmoid; depth 1x1 conv 1->24 + bilinear to 12x12) and MessagePassing.forward cod.py:1193-1205
