@@ -187,7 +187,9 @@ int bww_launch(const void* x, const void* du, float* dwt, float* db, int B, int 
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
   const int ncb = C / 128;
   const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
-  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 4), 2048 / ncb));
+  // every workgroup pays a fixed (K*K+1)*128-float LDS zero + global-atomic flush: keep ~512 workgroups in total and
+  // give each wave >= 4 strips so that cost is amortised (the flush is 25.6 KB of fp32 atomics per workgroup)
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 512 / ncb)));
   hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(256), 0, s, (const T*)x, (const T*)du, dwt, db, B, H, W, C);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
   return 0;

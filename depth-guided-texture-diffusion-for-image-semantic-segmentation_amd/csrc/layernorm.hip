@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int LN_MAX_NPL = 4;      // chunks per lane: covers C <= 1024 (fp32) / 2048 (bf16)
-constexpr int LN_BWD_MAX_GRID = 256;
+constexpr int LN_BWD_MAX_GRID = 1024;
 
 template <typename T>
 struct RowRegs {
@@ -191,14 +191,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int nblocks, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  int which = c / C, col = c % C;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += ws[((size_t)b * 2 + which) * C + col];
-  (which ? dbeta : dgamma)[col] = s;
+// ws is [nblocks][2*C]; one workgroup sums 64 columns: wave w takes rows w, w+4, ... (256-B coalesced row segments),
+// the four waves meet in LDS.  Deterministic (fixed summation order), unlike an atomic flush.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblocks, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < 2 * C) {
+    int b = wave;
+    for (; b + 4 < nblocks; b += 8) { s0 += ws[(size_t)b * 2 * C + col]; s1 += ws[(size_t)(b + 4) * 2 * C + col]; }
+    for (; b < nblocks; b += 4) s0 += ws[(size_t)b * 2 * C + col];
+  }
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && col < 2 * C) {
+    const float s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (col < C) dgamma[col] = s; else dbeta[col - C] = s;
+  }
 }
 
 struct LnGeom { int G, npl; int64_t rows_per_block; };
@@ -238,7 +249,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
   switch (g.npl) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; default: LN_BWD(4); }
 #undef LN_BWD
   DGTD_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((int)cdiv(2 * C, 256)), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, grid, C);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((int)cdiv(2 * C, 64)), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, grid, C);
   DGTD_CHECK_LAUNCH("layernorm_bwd_reduce");
   return 0;
 }

@@ -12,7 +12,7 @@ def _launch_fwd(x, wt, bias, aux, mode, K):
     y = torch.empty_like(x)
     L.call("dgtd_dwconv_fwd", L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(aux), L.ptr(y), B, H, W, C, K, mode,
            L.dtype_code(x), L.stream_ptr(), algo=("hbm", (3 if mode == 2 else 2) * x.element_size() * x.numel()),
-           key=f"dgtd_dwconv_fwd[k{K},mode{mode}]")
+           key=f"dgtd_dwconv_fwd[k{K},mode{mode},{H}x{W}x{C}]")
     return y
 
 
@@ -47,7 +47,7 @@ class _DwConvFn(Function):
         dwt = torch.zeros_like(wt)
         db = torch.zeros(C, dtype=torch.float32, device=x.device) if has_bias else None
         L.call("dgtd_dwconv_bwd_weight", L.ptr(x), L.ptr(du), L.ptr(dwt), L.ptr(db), B, H, W, C, K, L.dtype_code(x),
-               L.stream_ptr(), algo=("hbm", 2 * x.element_size() * x.numel()), key=f"dgtd_dwconv_bwd_weight[k{K}]")
+               L.stream_ptr(), algo=("hbm", 2 * x.element_size() * x.numel()), key=f"dgtd_dwconv_bwd_weight[k{K},{H}x{W}x{C}]")
         return dx, dwt.t().reshape(wshape), db, None
 
 

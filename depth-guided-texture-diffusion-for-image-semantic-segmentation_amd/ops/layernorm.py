@@ -21,7 +21,7 @@ class _LayerNormFn(Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         L.call("dgtd_layernorm_fwd", L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.ptr(mean), L.ptr(rstd),
                rows, C, float(eps), L.dtype_code(x), L.stream_ptr(),
-               algo=("hbm", 2 * x.element_size() * rows * C))
+               algo=("hbm", 2 * x.element_size() * rows * C), key=f"dgtd_layernorm_fwd[rows={rows},C={C}]")
         ctx.save_for_backward(x, w32, mean, rstd)
         return y
 
@@ -40,7 +40,7 @@ class _LayerNormFn(Function):
         ws = torch.empty(L.load().dgtd_layernorm_bwd_workspace(C), dtype=torch.uint8, device=x.device)
         L.call("dgtd_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(w32), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
                L.ptr(dg), L.ptr(db), L.ptr(ws), rows, C, L.dtype_code(x), L.stream_ptr(),
-               algo=("hbm", 3 * x.element_size() * rows * C))
+               algo=("hbm", 3 * x.element_size() * rows * C), key=f"dgtd_layernorm_bwd[rows={rows},C={C}]")
         return dx, dg, db, None
 
 
