@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 #pragma unroll
       for (int t = 0; t < TX; ++t) acc[t][j] = bv;
     }
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {   // not unrolled: keeps ~1 row of taps live -> high occupancy hides the L2 latency
       const int yy = yy0 + ky - P;
       if (yy < 0 || yy >= H) continue;
       const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
@@ -106,66 +106,69 @@ template <typename T, int K, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
                                                                 float* __restrict__ dwt, float* __restrict__ db,
                                                                 int B, int H, int W, int C) {
+  // blockIdx.y = 128-channel block, blockIdx.z = filter row ky: K accumulators x 2 channels per lane, so the kernel runs at
+  // full occupancy and K times more waves are in flight than with a whole-filter accumulator.
   typedef typename Pair<T>::type PT;
-  constexpr int P = K / 2, KK = K * K;
-  __shared__ float red[KK + 1][128];
+  constexpr int P = K / 2;
+  __shared__ float red[K + 1][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.y * 128 + lane * 2;
+  const int ky = blockIdx.z;
   const int XB = (W + TX - 1) / TX;
   const int64_t nstrips = (int64_t)B * H * XB;
-  for (int i = tid; i < (KK + 1) * 128; i += 256) (&red[0][0])[i] = 0.f;
-  float acc[KK][2], accb[2] = {0.f, 0.f};
+  for (int i = tid; i < (K + 1) * 128; i += 256) (&red[0][0])[i] = 0.f;
+  float acc[K][2], accb[2] = {0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < KK; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+  for (int t = 0; t < K; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
   for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < nstrips; s += (int64_t)gridDim.x * 4) {
     int64_t r = s;
     const int xb = (int)(r % XB); r /= XB;
     const int yy0 = (int)(r % H);
     const int b = (int)(r / H);
     const int x0 = xb * TX;
+    const int yy = yy0 + ky - P;
+    if (yy < 0 || yy >= H) continue;
     float g[TX][2];
     const T* grow = du + (((size_t)b * H + yy0) * W) * C + c0;
+    const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+    float in[TX + K - 1][2];
 #pragma unroll
     for (int t = 0; t < TX; ++t) {
       if (x0 + t < W) {
         PT v = *reinterpret_cast<const PT*>(grow + (size_t)(x0 + t) * C);
         g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
       } else { g[t][0] = 0.f; g[t][1] = 0.f; }
-      accb[0] += g[t][0]; accb[1] += g[t][1];
     }
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int yy = yy0 + ky - P;
-      if (yy < 0 || yy >= H) continue;
-      const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
-      float in[TX + K - 1][2];
+    for (int i = 0; i < TX + K - 1; ++i) {
+      const int xx = x0 + i - P;
+      if (xx >= 0 && xx < W) {
+        PT v = *reinterpret_cast<const PT*>(row + (size_t)xx * C);
+        in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
+      } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+    }
+    if (ky == P) {
 #pragma unroll
-      for (int i = 0; i < TX + K - 1; ++i) {
-        const int xx = x0 + i - P;
-        if (xx >= 0 && xx < W) {
-          PT v = *reinterpret_cast<const PT*>(row + (size_t)xx * C);
-          in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
-        } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+      for (int t = 0; t < TX; ++t) { accb[0] += g[t][0]; accb[1] += g[t][1]; }
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+      for (int t = 0; t < TX; ++t) {
+        acc[kx][0] += g[t][0] * in[t + kx][0];
+        acc[kx][1] += g[t][1] * in[t + kx][1];
       }
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-        for (int t = 0; t < TX; ++t) {
-          acc[ky * K + kx][0] += g[t][0] * in[t + kx][0];
-          acc[ky * K + kx][1] += g[t][1] * in[t + kx][1];
-        }
-    }
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < KK; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
-  atomicAdd(&red[KK][lane * 2], accb[0]); atomicAdd(&red[KK][lane * 2 + 1], accb[1]);
+  for (int t = 0; t < K; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
+  if (ky == P) { atomicAdd(&red[K][lane * 2], accb[0]); atomicAdd(&red[K][lane * 2 + 1], accb[1]); }
   __syncthreads();
-  for (int i = tid; i < (KK + 1) * 128; i += 256) {
+  for (int i = tid; i < (K + 1) * 128; i += 256) {
     const int t = i >> 7, c = i & 127;
     const float v = red[t][c];
-    if (t < KK) atomicAdd(&dwt[(size_t)t * C + blockIdx.y * 128 + c], v);
-    else if (db) atomicAdd(&db[blockIdx.y * 128 + c], v);
+    if (t < K) atomicAdd(&dwt[(size_t)(ky * K + t) * C + blockIdx.y * 128 + c], v);
+    else if (db && ky == P) atomicAdd(&db[blockIdx.y * 128 + c], v);
   }
 }
 
@@ -187,10 +190,9 @@ int bww_launch(const void* x, const void* du, float* dwt, float* db, int B, int 
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
   const int ncb = C / 128;
   const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
-  // every workgroup pays a fixed (K*K+1)*128-float LDS zero + global-atomic flush: keep ~512 workgroups in total and
-  // give each wave >= 4 strips so that cost is amortised (the flush is 25.6 KB of fp32 atomics per workgroup)
-  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 512 / ncb)));
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(256), 0, s, (const T*)x, (const T*)du, dwt, db, B, H, W, C);
+  // every workgroup pays a fixed (K+1)*128-float LDS zero + global-atomic flush: ~2048 workgroups in total, >= 4 strips per wave
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 2048 / (ncb * K))));
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb, K), dim3(256), 0, s, (const T*)x, (const T*)du, dwt, db, B, H, W, C);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
   return 0;
 }

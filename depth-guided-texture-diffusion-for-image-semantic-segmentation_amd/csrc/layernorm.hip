@@ -121,47 +121,56 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
     for (int j = 0; j < V; ++j) { gm[i][j] = (c < cpr) ? gamma[c * V + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; }
   }
-  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < rows; r0 += (int64_t)gridDim.x * rows_per_block) {
-    int64_t row = r0 + wave * rpw + gi;
-    bool ok = row < rows;
-    float xv[NPL][V], gv[NPL][V];
-    float mu = 0.f, rs = 0.f;
-    if (ok) {
-      load_row<T, NPL>(x + row * C, cpr, gl, G, xv);
-      load_row<T, NPL>(dy + row * C, cpr, gl, G, gv);
-      mu = mean[row]; rs = rstd[row];
-    } else {
+  constexpr int U = (NPL <= 2) ? 4 : 2;   // rows in flight per lane group: U independent row loads are issued before any reduction
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block * U; r0 < rows; r0 += (int64_t)gridDim.x * rows_per_block * U) {
+    float xv[U][NPL][V], gv[U][NPL][V], mu[U], rs[U];
+    bool ok[U];
 #pragma unroll
-      for (int i = 0; i < NPL; ++i)
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + (int64_t)u * rows_per_block + wave * rpw + gi;
+      ok[u] = row < rows;
+      if (ok[u]) {
+        load_row<T, NPL>(x + row * C, cpr, gl, G, xv[u]);
+        load_row<T, NPL>(dy + row * C, cpr, gl, G, gv[u]);
+        mu[u] = mean[row]; rs[u] = rstd[row];
+      } else {
+        mu[u] = 0.f; rs[u] = 0.f;
 #pragma unroll
-        for (int j = 0; j < V; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
-    }
-    float a = 0.f, b = 0.f;
+        for (int i = 0; i < NPL; ++i)
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      bool in = (gl + i * G) < cpr;
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        float xh = in ? (xv[i][j] - mu) * rs : 0.f;
-        float g = gv[i][j];
-        dg[i][j] += g * xh;
-        db[i][j] += g;
-        g *= gm[i][j];
-        a += g; b += g * xh;
-        xv[i][j] = xh; gv[i][j] = g;
+          for (int j = 0; j < V; ++j) { xv[u][i][j] = 0.f; gv[u][i][j] = 0.f; }
       }
     }
-    a = group_sum(a, G) * invC;
-    b = group_sum(b, G) * invC;
-    if (ok) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float a = 0.f, b = 0.f;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        int c = gl + i * G;
-        if (c < cpr) {
-          VT o;
+        bool in = (gl + i * G) < cpr;
 #pragma unroll
-          for (int j = 0; j < V; ++j) o[j] = (T)(rs * (gv[i][j] - a - xv[i][j] * b));
-          *reinterpret_cast<VT*>(dx + row * C + (size_t)c * V) = o;
+        for (int j = 0; j < V; ++j) {
+          float xh = in ? (xv[u][i][j] - mu[u]) * rs[u] : 0.f;
+          float g = gv[u][i][j];
+          dg[i][j] += g * xh;
+          db[i][j] += g;
+          g *= gm[i][j];
+          a += g; b += g * xh;
+          xv[u][i][j] = xh; gv[u][i][j] = g;
+        }
+      }
+      a = group_sum(a, G) * invC;
+      b = group_sum(b, G) * invC;
+      if (ok[u]) {
+        const int64_t row = r0 + (int64_t)u * rows_per_block + wave * rpw + gi;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          int c = gl + i * G;
+          if (c < cpr) {
+            VT o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = (T)(rs[u] * (gv[u][i][j] - a - xv[u][i][j] * b));
+            *reinterpret_cast<VT*>(dx + row * C + (size_t)c * V) = o;
+          }
         }
       }
     }
@@ -243,7 +252,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
   LnGeom g = ln_geom<T>(C);
   DGTD_REQUIRE(g.npl <= LN_MAX_NPL, "layernorm: C=%d too large", C);
   DGTD_REQUIRE(rows > 0, "layernorm_bwd: rows must be > 0");
-  int grid = (int)std::min<int64_t>(cdiv(rows, g.rows_per_block), LN_BWD_MAX_GRID);
+  int grid = (int)std::min<int64_t>(cdiv(rows, g.rows_per_block * 4), LN_BWD_MAX_GRID);
   size_t lds = (size_t)4 * 2 * C * sizeof(float);
 #define LN_BWD(NPL) hipLaunchKernelGGL((ln_bwd_kernel<T, NPL>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (float*)ws, rows, C, g.G)
   switch (g.npl) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; default: LN_BWD(4); }
