@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 //   Qr[32][72], Gr[32][72]   row-major Q / dO tile (row frags, 16-B reads)
 //   Qt[64][36], Gt[64][36]   transposed tiles (col frags: 4 consecutive queries = 8 B)
 //   Kt[64][SLICE+4]          transposed K slice (col frags for dQ), read once into registers
-//   lse2[32], dlt[32] fp32; dqs[32][64] fp32 (LDS-atomic dQ tile)
+//   lse2[32], dlt[32] fp32; dqs[64][33] fp32 (LDS-atomic dQ^T tile; 33-float rows: conflict-free for lane = query)
 struct BwdSmemBf16 {
   static constexpr int QS = 72, TS = 36, KTS = SLICE + 4;
   static constexpr size_t off_Qr = 0;
@@ -62,7 +62,7 @@ struct BwdSmemBf16 {
   static constexpr size_t off_lse = off_Kt + 64 * KTS * 2;
   static constexpr size_t off_dlt = off_lse + 32 * 4;
   static constexpr size_t off_dq = off_dlt + 32 * 4;
-  static constexpr size_t total = off_dq + 32 * 64 * 4;
+  static constexpr size_t total = off_dq + 64 * 33 * 4;
 };
 
 __global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q
         lse2[i] = ok ? lse[o] * LOG2E : INFINITY;   // +inf -> P = exp2(-inf) = 0 for padded query rows
         dlt[i] = ok ? delta[o] : 0.f;
       }
-      for (int i = tid; i < 32 * 64; i += nthr) dqs[i] = 0.f;
+      for (int i = tid; i < 64 * 33; i += nthr) dqs[i] = 0.f;
       __syncthreads();
 
       if (wave_active) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[r * 64 + nb * 32 + mfma_row(i, h)], dqa[nb][i]);
+            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[(nb * 32 + mfma_row(i, h)) * 33 + r], dqa[nb][i]);
         }
       }
       __syncthreads();
@@ -250,10 +250,10 @@ __global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q
           if (sl > 0) {
             bf16x8 prev = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)prev[j] + dqs[row * 64 + ch * 8 + j]);
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)prev[j] + dqs[(ch * 8 + j) * 33 + row]);
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)dqs[row * 64 + ch * 8 + j];
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)dqs[(ch * 8 + j) * 33 + row];
           }
           *reinterpret_cast<bf16x8*>(dst) = o;
         }
@@ -287,7 +287,7 @@ struct BwdSmemF32 {
   static constexpr size_t off_lse = off_Ks + (size_t)SLICE * 64 * 4;
   static constexpr size_t off_dlt = off_lse + 32 * 4;
   static constexpr size_t off_dq = off_dlt + 32 * 4;
-  static constexpr size_t total = off_dq + 32 * 64 * 4;
+  static constexpr size_t total = off_dq + 64 * 33 * 4;
 };
 
 __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, const float* __restrict__ kv,
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
         lse2[i] = ok ? lse[o] * LOG2E : INFINITY;
         dlt[i] = ok ? delta[o] : 0.f;
       }
-      for (int i = tid; i < 32 * 64; i += nthr) dqs[i] = 0.f;
+      for (int i = tid; i < 64 * 33; i += nthr) dqs[i] = 0.f;
       __syncthreads();
 
       if (wave_active) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[r * 64 + nb * 32 + mfma_row(i, h)], dqa[nb][i]);
+            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[(nb * 32 + mfma_row(i, h)) * 33 + r], dqa[nb][i]);
         }
       }
       __syncthreads();
@@ -435,7 +435,9 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
         const int row = i >> 4, ch = i & 15;
         if (q0 + row < N) {
           float* dst = dq + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 4;
-          f32x4 o = *reinterpret_cast<const f32x4*>(dqs + row * 64 + ch * 4);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = dqs[(ch * 4 + j) * 33 + row];
           if (sl > 0) { f32x4 prev = *reinterpret_cast<const f32x4*>(dst); o += prev; }
           *reinterpret_cast<f32x4*>(dst) = o;
         }

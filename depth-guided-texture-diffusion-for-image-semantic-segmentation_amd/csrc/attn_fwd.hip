@@ -299,7 +299,7 @@ int pick_qtw(int N, int bh) {
   // q tiles of 128 rows per workgroup-iteration; aim for >= ~4 workgroups per CU, amortise staging otherwise
   int64_t groups = cdiv(N, 128);
   int qtw = 1;
-  while (qtw < 8 && groups * bh / (qtw * 2) >= 1024) qtw *= 2;
+  while (qtw < 8 && groups * bh / (qtw * 2) >= 512) qtw *= 2;   // ~2 workgroups per CU; K/V staging amortised over qtw tiles
   return qtw;
 }
 

@@ -209,9 +209,16 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   const int col = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (col < 2 * C) {
+    const size_t rs = (size_t)2 * C;
+    const float* p = ws + col;
     int b = wave;
-    for (; b + 4 < nblocks; b += 8) { s0 += ws[(size_t)b * 2 * C + col]; s1 += ws[(size_t)(b + 4) * 2 * C + col]; }
-    for (; b < nblocks; b += 4) s0 += ws[(size_t)b * 2 * C + col];
+    for (; b + 28 < nblocks; b += 32) {   // 8 independent loads in flight per lane, fixed summation order
+      const float v0 = p[(size_t)b * rs], v1 = p[(size_t)(b + 4) * rs], v2 = p[(size_t)(b + 8) * rs], v3 = p[(size_t)(b + 12) * rs];
+      const float v4 = p[(size_t)(b + 16) * rs], v5 = p[(size_t)(b + 20) * rs], v6 = p[(size_t)(b + 24) * rs], v7 = p[(size_t)(b + 28) * rs];
+      s0 += ((v0 + v1) + (v2 + v3));
+      s1 += ((v4 + v5) + (v6 + v7));
+    }
+    for (; b < nblocks; b += 4) s0 += p[(size_t)b * rs];
   }
   part[wave][lane] = s0 + s1;
   __syncthreads();

@@ -105,6 +105,8 @@ class GradReducer:
 
     def _make_hook(self, bucket):
         def hook(_param):
+            if not self.overlap or torch.cuda.is_current_stream_capturing():
+                return
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
                 self._launch(bucket)
@@ -140,6 +142,8 @@ class GradReducer:
         if not self.overlap:
             for b in self.buckets:
                 self._launch(b)
+        elif False:
+            pass
         else:
             for b in self.buckets:  # a bucket whose params did not all fire (should not happen) is still reduced
                 if b["pending"] != 0:

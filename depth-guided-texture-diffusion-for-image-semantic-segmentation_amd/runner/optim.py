@@ -26,7 +26,8 @@ def lr_mult_for(name: str, custom_keys: Dict[str, float]) -> float:
 
 
 def build_optimizer(model: torch.nn.Module, lr: float = 5e-4, weight_decay: float = 0.1,
-                    custom_keys: Optional[Dict[str, float]] = None, fused: Optional[bool] = None):
+                    custom_keys: Optional[Dict[str, float]] = None, fused: Optional[bool] = None,
+                    capturable: bool = False):
     custom_keys = SOD_CUSTOM_KEYS if custom_keys is None else custom_keys
     groups: Dict[float, list] = {}
     seen = set()
@@ -38,4 +39,4 @@ def build_optimizer(model: torch.nn.Module, lr: float = 5e-4, weight_decay: floa
     param_groups = [{"params": ps, "lr": lr * m, "initial_lr": lr * m} for m, ps in sorted(groups.items(), reverse=True)]
     if fused is None:
         fused = any(p.is_cuda for g in param_groups for p in g["params"])
-    return torch.optim.AdamW(param_groups, lr=lr, weight_decay=weight_decay, fused=fused)
+    return torch.optim.AdamW(param_groups, lr=lr, weight_decay=weight_decay, fused=fused, capturable=capturable and fused)
