@@ -35,8 +35,6 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--graph", action="store_true",
-                    help="capture zero_grad+forward+loss+backward in one hipGraph (RCCL all-reduce and AdamW stay outside it)")
     return ap.parse_args()
 
 
@@ -78,7 +76,7 @@ def main():
     torch.manual_seed(0)
     net = dgtd.nn.cod(compute_dtype=dtype).to(dev).train()   # random init of the reference architecture, DropPath active
     dgtd.dist.broadcast_parameters(net)
-    reducer = dgtd.dist.GradReducer(net)
+    reducer = dgtd.dist.GradReducer(net, working_dtype=dtype)
     opt = dgtd.runner.build_optimizer(net)
     data = dgtd.runner.SyntheticRGBD(args.size, args.batch, rank=rank, device=dev)
     batches = [data.batch_at(i) for i in range(2)]  # resident in HBM before timing
@@ -89,19 +87,12 @@ def main():
         loss.backward()
         return loss
 
-    graph, static, static_loss = None, None, None
-
     def step(i):
         b = batches[i % len(batches)]
-        if graph is not None:
-            for k in ("input", "label", "depth"):
-                static[k].copy_(torch.stack(b[k]))
-            graph.replay()
-            loss = static_loss
-        else:
-            loss = fwd_bwd(b)
+        loss = fwd_bwd(b)
         reducer.finish()
         opt.step()
+        reducer.refresh_working()
         return loss
 
     def barrier():
@@ -112,25 +103,6 @@ def main():
     def log(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
-
-    if args.graph:
-        # hipGraph capture of the launch-bound part of the step.  Collectives and the optimizer are launched eagerly
-        # after the replay, so the multi-GPU path never captures RCCL calls.
-        static = {k: torch.stack(batches[0][k]).clone() for k in ("input", "label", "depth")}
-        static["raw"] = batches[0]["raw"]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fwd_bwd(static)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        reducer.overlap = False  # hooks cannot launch collectives from inside a replay; finish() reduces after it
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            static_loss = fwd_bwd(static)
-        graph = g
-        log("captured zero_grad+forward+loss+backward into one hipGraph")
 
     for i in range(args.warmup):
         tw = time.perf_counter()
@@ -192,7 +164,7 @@ def main():
             "config": {"workload": f"config/sod.yml model `cod` (PVTv2-b2 + ConvNeXt-B texture diffuser + Hitnet decoder), "
                                    f"{args.size}x{args.size} RGB+depth, batch {args.batch}/GPU, random init, DropPath active",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
-                       "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2), "hipgraph": bool(args.graph),
+                       "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2),
                        "tflops_sustained": round(imgs / dt * 786.7e9 * (args.size / 512) ** 2 / 1e12, 2)},
             "roofline": roofline, "kernels": kernels[:12],
         }

@@ -1,21 +1,24 @@
-"""Bucketed gradient all-reduce for the single-node data-parallel training step.
+"""Bucketed gradient handling for the single-node data-parallel training step.
 
 The reference gets this from mmengine's MMDistributedDataParallel with find_unused_parameters=True
-(config/sod.yml:11): a per-step graph walk plus a per-step BN-buffer broadcast.  Here:
-  * gradients live in flat per-bucket buffers (``param.grad`` is a view), so a bucket is reduced in place
-    with ONE collective and no gather/scatter copies;
-  * buckets follow reverse registration order (≈ gradient-readiness: Hitnet heads -> PVT stage 4..1 ->
-    prompt decoders -> ConvNeXt 3..0 -> diffuser 1x1s), and each is launched from an autograd
-    post-accumulate hook on a side HIP stream fenced by events, so RCCL traffic over xGMI overlaps the rest
-    of the backward;
-  * the parameters that never receive a gradient (5 tensors) are excluded statically instead of
-    being discovered every step;
-  * BatchNorm statistics stay per-rank (the reference uses plain BatchNorm2d, cod.py:362) and are not broadcast.
+(config/sod.yml:11) plus AmpOptimWrapper (config/sod.yml:57): a per-step graph walk, a per-step BN-buffer
+broadcast, one cast kernel per weight per forward and one accumulate kernel per parameter per backward.
+Here, per bucket (reverse registration order ≈ gradient readiness: Hitnet heads -> PVT stage 4..1 -> prompt
+decoders -> ConvNeXt 3..0 -> diffuser 1x1s):
+  * fp32 MASTER parameters stay the modules' registered parameters (state_dict contract, optimizer state);
+  * Linear/Conv2d weights and biases get a low-precision WORKING COPY (leaf tensors inside one flat buffer),
+    refreshed with ONE multi-tensor cast per bucket after the optimizer step; the modules compute with it;
+  * autograd hands every leaf its gradient without an accumulate kernel (``.grad`` is None before backward);
+    when the last leaf of a bucket is ready, ONE multi-tensor copy casts the bucket's gradients into a flat
+    fp32 buffer, and (N > 1) ONE all-reduce is launched on a side HIP stream fenced by events, so RCCL traffic
+    over xGMI overlaps the rest of the backward;  master ``.grad``s are views of that flat buffer;
+  * the parameters that never receive a gradient (5 tensors) are excluded statically;
+  * BatchNorm statistics stay per-rank (plain BatchNorm2d, cod.py:362) and are not broadcast.
 """
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -45,11 +48,10 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """One-time replica sync (parameters AND buffers) from rank ``src``; coalesced into few large messages."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
     by_dtype = {}
-    for t in tensors:
+    for t in list(module.parameters()) + list(module.buffers()):
         by_dtype.setdefault(t.dtype, []).append(t)
-    for dtype, ts in by_dtype.items():
+    for ts in by_dtype.values():
         flat = torch.cat([t.detach().reshape(-1) for t in ts])
         dist.broadcast(flat, src, group=group)
         off = 0
@@ -60,16 +62,26 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
 
 
 class GradReducer:
-    """Owns flat gradient buckets for ``module`` and averages them across the process group."""
+    """Flat gradient buckets (+ optional low-precision working weights) for ``module``."""
 
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 64 << 20, group=None,
-                 exclude_prefixes: Sequence[str] = STATIC_UNUSED, overlap: bool = True):
+                 exclude_prefixes: Sequence[str] = STATIC_UNUSED, overlap: bool = True,
+                 working_dtype: Optional[torch.dtype] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.working_dtype = working_dtype if working_dtype not in (None, torch.float32) else None
+        # parameters that the modules consume through wb(): weights / biases of the package's Linear / Conv2d
+        castable = {}
+        if self.working_dtype is not None:
+            from ..nn.modules import Conv2d, Linear
+            for m in module.modules():
+                if isinstance(m, (Linear, Conv2d)):
+                    castable[id(m.weight)] = (m, "_w")
+                    if m.bias is not None:
+                        castable[id(m.bias)] = (m, "_b")
         seen, params = set(), []
-        for n, p in named:  # named_parameters() already de-duplicates the shared PReLU
-            if id(p) in seen or any(n.startswith(e) for e in exclude_prefixes):
+        for n, p in module.named_parameters():  # named_parameters() de-duplicates the shared PReLU
+            if not p.requires_grad or id(p) in seen or any(n.startswith(e) for e in exclude_prefixes):
                 continue
             seen.add(id(p))
             params.append((n, p))
@@ -80,39 +92,93 @@ class GradReducer:
             cur.append((n, p))
             cur_bytes += p.numel() * p.element_size()
             if cur_bytes >= bucket_bytes:
-                self._seal(cur)
+                self._seal(cur, castable)
                 cur, cur_bytes = [], 0
         if cur:
-            self._seal(cur)
+            self._seal(cur, castable)
         self.overlap = overlap and self.world > 1
         self._cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self._cuda and self.overlap) else None
         self._works = []
-        if self.overlap:
-            for b in self.buckets:
-                for _, p in b["params"]:
-                    p.register_post_accumulate_grad_hook(self._make_hook(b))
+        for b in self.buckets:
+            for leaf in b["leaves"]:
+                leaf.register_post_accumulate_grad_hook(self._make_hook(b))
+        self.refresh_working()
 
-    def _seal(self, items) -> None:
+    # ------------------------------------------------------------------ construction
+    def _seal(self, items, castable) -> None:
         p0 = items[0][1]
         total = sum(p.numel() for _, p in items)
-        flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
-        off = 0
+        flat = torch.zeros(total, dtype=torch.float32, device=p0.device)
+        masters, leaves, gviews, w_masters, w_leaves = [], [], [], [], []
+        n_work = sum(p.numel() for _, p in items if id(p) in castable)
+        wflat = torch.zeros(n_work, dtype=self.working_dtype, device=p0.device) if n_work else None
+        off = woff = 0
         for _, p in items:
-            p.grad = flat[off:off + p.numel()].view_as(p)  # gradient-as-bucket-view
+            gv = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self.buckets.append({"flat": flat, "params": items, "pending": len(items), "n": len(items)})
+            p.grad = gv                      # master .grad = view of the flat fp32 bucket (what the optimizer reads)
+            masters.append(p)
+            gviews.append(gv)
+            if id(p) in castable:
+                m, attr = castable[id(p)]
+                leaf = wflat[woff:woff + p.numel()].view_as(p)
+                woff += p.numel()
+                leaf.requires_grad_(True)    # a leaf: its base buffer does not require grad
+                object.__setattr__(m, attr, leaf)
+                p.requires_grad_(False)      # the master no longer takes part in autograd
+                w_masters.append(p)
+                w_leaves.append(leaf)
+                leaves.append(leaf)
+            else:
+                leaves.append(p)
+        self.buckets.append({"flat": flat, "masters": masters, "leaves": leaves, "gviews": gviews, "w_masters": w_masters,
+                             "w_leaves": w_leaves, "pending": len(items), "n": len(items), "done": False})
+
+    # ------------------------------------------------------------------ per step
+    @torch.no_grad()
+    def refresh_working(self) -> None:
+        """master fp32 -> working copy: one multi-tensor cast per bucket (call after optimizer.step())."""
+        for b in self.buckets:
+            if b["w_leaves"]:
+                torch._foreach_copy_(b["w_leaves"], b["w_masters"])
+
+    def zero_grad(self) -> None:
+        """Replaces optimizer.zero_grad(): leaves get .grad = None so autograd hands gradients over without an
+        accumulate kernel; nothing is memset (the flat buckets are fully overwritten by _gather)."""
+        for b in self.buckets:
+            b["pending"], b["done"] = b["n"], False
+            for leaf in b["leaves"]:
+                leaf.grad = None
 
     def _make_hook(self, bucket):
-        def hook(_param):
-            if not self.overlap or torch.cuda.is_current_stream_capturing():
-                return
+        def hook(_leaf):
             bucket["pending"] -= 1
-            if bucket["pending"] == 0:
+            if bucket["pending"] == 0 and self.overlap:
+                self._gather(bucket)
                 self._launch(bucket)
         return hook
 
+    @torch.no_grad()
+    def _gather(self, bucket) -> None:
+        """leaf gradients (any dtype) -> flat fp32 bucket with one multi-tensor copy; restore master .grad views."""
+        grads, views = [], []
+        for leaf, gv in zip(bucket["leaves"], bucket["gviews"]):
+            if leaf.grad is None:
+                gv.zero_()              # parameter unused this step
+            else:
+                grads.append(leaf.grad)
+                views.append(gv)
+        if grads:
+            torch._foreach_copy_(views, grads)
+        for p, leaf, gv in zip(bucket["masters"], bucket["leaves"], bucket["gviews"]):
+            leaf.grad = None            # free the per-leaf gradient
+            p.grad = gv
+        bucket["done"] = True
+
     def _launch(self, bucket) -> None:
+        if self.world == 1:
+            return
         flat = bucket["flat"]
         if self._cuda and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -124,30 +190,12 @@ class GradReducer:
             w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
 
-    def zero_grad(self) -> None:
-        """Replaces optimizer.zero_grad(): one memset per bucket, grads stay views of the flat buffers."""
-        for b in self.buckets:
-            b["flat"].zero_()
-            b["pending"] = b["n"]
-            off = 0
-            for _, p in b["params"]:
-                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * b["flat"].element_size():
-                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
-                off += p.numel()
-
     def finish(self) -> None:
-        """Call after backward(): launches anything not launched by hooks and fences the compute stream."""
-        if self.world == 1:
-            return
-        if not self.overlap:
-            for b in self.buckets:
+        """Call after backward(): gathers/launches whatever the hooks did not, then fences the compute stream."""
+        for b in self.buckets:
+            if not b["done"]:
+                self._gather(b)
                 self._launch(b)
-        elif False:
-            pass
-        else:
-            for b in self.buckets:  # a bucket whose params did not all fire (should not happen) is still reduced
-                if b["pending"] != 0:
-                    self._launch(b)
         for w in self._works:
             w.wait()
         self._works.clear()

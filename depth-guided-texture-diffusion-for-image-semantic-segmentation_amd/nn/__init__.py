@@ -1,6 +1,6 @@
 """Drop-in nn.Module replacements for the reference's hot path (twig/model/cod.py): same class names,
 constructor/forward signatures and state_dict keys, backed by the gfx950 kernels in libdgtd.so."""
-from .modules import (Attention, BasicConv2d, Block, CAB, CALayer, DropPath, DWConv, Hitnet, LayerNorm,  # noqa: F401
+from .modules import (Attention, Linear, Conv2d, wb, BasicConv2d, Block, CAB, CALayer, DropPath, DWConv, Hitnet, LayerNorm,  # noqa: F401
                       MessagePassing, Mlp, OverlapPatchEmbed, PyramidVisionTransformerImpr, SAM, ShapePropDecoder,
                       ShapePropEncoder, ShapePropWeightRegressor, cod, convnext_Block, prompt_decoder, prompt_encoder,
                       pvt_v2_b2, cal_loss, ssim_value, fft_highpass)

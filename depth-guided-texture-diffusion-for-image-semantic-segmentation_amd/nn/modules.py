@@ -35,6 +35,34 @@ class DropPath(nn.Module):
         return x * mask.div_(keep)
 
 
+class Linear(nn.Linear):
+    """nn.Linear whose compute can run on a low-precision WORKING COPY of the fp32 master parameters.
+    ``_w``/``_b`` are plain attributes installed by dist.GradReducer (not parameters, not in state_dict)."""
+    _w = None
+    _b = None
+
+    def forward(self, x):
+        return F.linear(x, *wb(self))
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d with the same optional working copy."""
+    _w = None
+    _b = None
+
+    def forward(self, x):
+        w, b = wb(self)
+        return self._conv_forward(x, w, b)
+
+
+def wb(m):
+    """(weight, bias) to compute with: the working copy when one is installed, else the master parameters."""
+    w = m._w
+    if w is None:
+        return m.weight, m.bias
+    return w, m._b
+
+
 def _init_weights(m: nn.Module) -> None:
     """cod.py:1401-1414."""
     if isinstance(m, nn.Linear):
@@ -90,7 +118,7 @@ class OverlapPatchEmbed(nn.Module):
     def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
         super().__init__()
         self.patch_size, self.stride = patch_size, stride
-        self.proj = nn.Conv2d(in_chans, embed_dim, patch_size, stride, patch_size // 2)
+        self.proj = Conv2d(in_chans, embed_dim, patch_size, stride, patch_size // 2)
         self.norm = LayerNorm(embed_dim, eps=1e-5)
         self.apply(_init_weights)
 
@@ -111,18 +139,19 @@ class Attention(nn.Module):
         assert attn_drop == 0. and proj_drop == 0., "reference configs use zero dropout (cod.py:1787)"
         self.dim, self.num_heads, self.sr_ratio = dim, num_heads, sr_ratio
         self.scale = qk_scale or (dim // num_heads) ** -0.5
-        self.q = nn.Linear(dim, dim, bias=qkv_bias)
-        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
-        self.proj = nn.Linear(dim, dim)
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
         if sr_ratio > 1:
-            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.sr = Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = LayerNorm(dim, eps=1e-5)
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
         q = self.q(x)
         if self.sr_ratio > 1:  # k == s conv == patchify + GEMM, stays token-major
-            r = F.linear(_patchify(x, H, W, self.sr_ratio), self.sr.weight.flatten(1), self.sr.bias)
+            w, b = wb(self.sr)
+            r = F.linear(_patchify(x, H, W, self.sr_ratio), w.flatten(1), b)
             r = self.norm(r)
         else:
             r = x
@@ -135,11 +164,11 @@ class DWConv(nn.Module):
 
     def __init__(self, dim=768):
         super().__init__()
-        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+        self.dwconv = Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
     def forward(self, x, H, W, gelu: bool = False):
         B, N, Cc = x.shape
-        return ops.dwconv_nhwc(x.view(B, H, W, Cc), self.dwconv.weight, self.dwconv.bias, gelu).view(B, N, Cc)
+        return ops.dwconv_nhwc(x.view(B, H, W, Cc), *wb(self.dwconv), gelu).view(B, N, Cc)
 
 
 class Mlp(nn.Module):
@@ -149,9 +178,9 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = Linear(in_features, hidden_features)
         self.dwconv = DWConv(hidden_features)
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = Linear(hidden_features, out_features)
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
@@ -183,15 +212,15 @@ class convnext_Block(nn.Module):
 
     def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6):
         super().__init__()
-        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.dwconv = Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
         self.norm = LayerNorm(dim, eps=1e-6)
-        self.pwconv1 = nn.Linear(dim, 4 * dim)
-        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.pwconv1 = Linear(dim, 4 * dim)
+        self.pwconv2 = Linear(4 * dim, dim)
         self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward_nhwc(self, x):
-        y = ops.dwconv_nhwc(x, self.dwconv.weight, self.dwconv.bias)
+        y = ops.dwconv_nhwc(x, *wb(self.dwconv))
         y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
         if self.gamma is not None:
             y = self.gamma.to(y.dtype) * y
@@ -209,16 +238,16 @@ class ShapePropEncoder(nn.Module):
         dims, depths = [128, 256, 512, 1024], [3, 3, 27, 3]
         self.dims = dims
         self.downsample_layers = nn.ModuleList(
-            [nn.Sequential(nn.Conv2d(3, dims[0], kernel_size=4, stride=4), LayerNorm(dims[0], eps=1e-6, data_format="channels_first"))]
+            [nn.Sequential(Conv2d(3, dims[0], kernel_size=4, stride=4), LayerNorm(dims[0], eps=1e-6, data_format="channels_first"))]
             + [nn.Sequential(LayerNorm(dims[i], eps=1e-6, data_format="channels_first"),
-                             nn.Conv2d(dims[i], dims[i + 1], kernel_size=2, stride=2)) for i in range(3)])
+                             Conv2d(dims[i], dims[i + 1], kernel_size=2, stride=2)) for i in range(3)])
         rates = [x.item() for x in torch.linspace(0, 0.4, sum(depths))]  # cod.py:1140-1145
         self.stages, cur = nn.ModuleList(), 0
         for i in range(4):
             self.stages.append(nn.Sequential(*[convnext_Block(dims[i], rates[cur + j], 1.0) for j in range(depths[i])]))
             cur += depths[i]
-        self.convs = nn.ModuleList([nn.Conv2d(dims[i], out_dim, 1) for i in range(4)])
-        self.fusion_conv = nn.Conv2d(out_dim * 4, out_dim, 1)
+        self.convs = nn.ModuleList([Conv2d(dims[i], out_dim, 1) for i in range(4)])
+        self.fusion_conv = Conv2d(out_dim * 4, out_dim, 1)
 
     def forward(self, x):
         B, _, H, W = x.shape
@@ -226,12 +255,14 @@ class ShapePropEncoder(nn.Module):
         # stem: conv k4 s4 == patchify + GEMM
         conv, norm = self.downsample_layers[0]
         t = x.view(B, 3, H // 4, 4, W // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 4) * (W // 4), 48)
-        t = norm(F.linear(t, conv.weight.flatten(1), conv.bias))
+        w, b = wb(conv)
+        t = norm(F.linear(t, w.flatten(1), b))
         h, w = H // 4, W // 4
         for i in range(4):
             if i > 0:
                 norm, conv = self.downsample_layers[i]
-                t = F.linear(_patchify(norm(t), h, w, 2), conv.weight.flatten(1), conv.bias)
+                cw, cb = wb(conv)
+                t = F.linear(_patchify(norm(t), h, w, 2), cw.flatten(1), cb)
                 h, w = h // 2, w // 2
             t4 = t.view(B, h, w, -1)
             for blk in self.stages[i]:
@@ -241,8 +272,8 @@ class ShapePropEncoder(nn.Module):
         size = (outs[0][1], outs[0][2])
         taps = []
         for (t, h, w), conv in zip(outs, self.convs):  # 1x1 conv == GEMM on tokens, then bilinear to stride 4
-            y = F.linear(t, conv.weight.flatten(1), conv.bias)
-            y = _tokens_to_nchw(y, h, w)
+            cw, cb = wb(conv)
+            y = _tokens_to_nchw(F.linear(t, cw.flatten(1), cb), h, w)
             taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
         return self.fusion_conv(torch.cat(taps, dim=1))
 
@@ -253,7 +284,7 @@ class ShapePropWeightRegressor(nn.Module):
     def __init__(self, in_channels, latent_dim):
         super().__init__()
         self.latent_dim = latent_dim
-        self.reg = nn.Conv2d(in_channels, latent_dim * 49, kernel_size=1)
+        self.reg = Conv2d(in_channels, latent_dim * 49, kernel_size=1)
 
     def forward(self, x):
         return torch.sigmoid(self.reg(x))
@@ -266,7 +297,7 @@ class MessagePassing(nn.Module):
         super().__init__()
         assert not sym_norm, "the reference's sym_norm branch references undefined attributes (cod.py:1194-1198)"
         self.k, self.size, self.max_step, self.img_size = k, k * k, max_step, img_size
-        self.conv = nn.Conv2d(latent_dim, 3, 1)
+        self.conv = Conv2d(latent_dim, 3, 1)
 
     def forward(self, input, weight):
         n, c, h, w = input.shape
@@ -296,9 +327,9 @@ class prompt_encoder(nn.Module):
         super().__init__()
         self.embed_dim, self.depth = embed_dim, depth
         self.propagation_weight_regressor = ShapePropWeightRegressor(3, latent_dim)
-        self.encoder1 = nn.Conv2d(1, latent_dim, 1)
+        self.encoder1 = Conv2d(1, latent_dim, 1)
         self.encoder2 = ShapePropEncoder(3, 24)
-        self.adaptor = nn.Conv2d(6, 3, 1)  # constructed, never called (cod.py:1251)
+        self.adaptor = Conv2d(6, 3, 1)  # constructed, never called (cod.py:1251)
         self.message_passing = MessagePassing(latent_dim, img_size=384, sym_norm=False)
         self.freq_nums = 0.3
 
@@ -311,10 +342,10 @@ class prompt_encoder(nn.Module):
             x = self.fft(image32, self.freq_nums)
             # one fused launch per (image, latent channel): regressor + depth embedding + 4 propagation steps
             reg = self.propagation_weight_regressor.reg
-            x4 = ops.diffuser_state(x, cues, reg.weight, reg.bias, self.encoder1.weight, self.encoder1.bias)
+            x4 = ops.diffuser_state(x, cues, *wb(reg), *wb(self.encoder1))
             # 1x1 conv 24->3, bilinear 12 -> S (the reference pins 384, cod.py:1252), + image: one HBM-bound pass
             mp = self.message_passing.conv
-            fused = ops.diffuse_tail(x4, mp.weight, mp.bias, image32)
+            fused = ops.diffuse_tail(x4, *wb(mp), image32)
         return x, self.encoder2(fused)
 
 
@@ -323,9 +354,9 @@ class ShapePropDecoder(nn.Module):
 
     def __init__(self, out_dim, latent_dim):
         super().__init__()
-        self.decoder = nn.Sequential(nn.Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
-                                     nn.Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
-                                     nn.Conv2d(latent_dim, out_dim, 3, 1, 1))
+        self.decoder = nn.Sequential(Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
+                                     Conv2d(latent_dim, latent_dim, 3, 1, 1), nn.ReLU(True),
+                                     Conv2d(latent_dim, out_dim, 3, 1, 1))
 
     def forward(self, embedding):
         return self.decoder(embedding)
@@ -406,7 +437,7 @@ class BasicConv2d(nn.Module):
 
     def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, dilation=1):
         super().__init__()
-        self.conv = nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, dilation, bias=False)
+        self.conv = Conv2d(in_planes, out_planes, kernel_size, stride, padding, dilation, bias=False)
         self.bn = nn.BatchNorm2d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
@@ -420,8 +451,8 @@ class CALayer(nn.Module):
     def __init__(self, channel, reduction=16, bias=False):
         super().__init__()
         self.avg_pool = nn.AdaptiveAvgPool2d(1)
-        self.conv_du = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1, bias=bias), nn.ReLU(inplace=True),
-                                     nn.Conv2d(channel // reduction, channel, 1, bias=bias), nn.Sigmoid())
+        self.conv_du = nn.Sequential(Conv2d(channel, channel // reduction, 1, bias=bias), nn.ReLU(inplace=True),
+                                     Conv2d(channel // reduction, channel, 1, bias=bias), nn.Sigmoid())
 
     def forward(self, x):
         return x * self.conv_du(self.avg_pool(x))
@@ -434,8 +465,8 @@ class CAB(nn.Module):
         super().__init__()
         pad = kernel_size // 2
         self.CA = CALayer(n_feat, reduction, bias=bias)
-        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias), act,
-                                  nn.Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias))
+        self.body = nn.Sequential(Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias), act,
+                                  Conv2d(n_feat, n_feat, kernel_size, padding=pad, bias=bias))
 
     def forward(self, x):
         return self.CA(self.body(x)) + x
@@ -447,10 +478,10 @@ class SAM(nn.Module):
     def __init__(self, ch_in=32, reduction=16):
         super().__init__()
         self.avg_pool = nn.AdaptiveAvgPool2d(1)
-        self.fc = nn.Sequential(nn.Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
-                                nn.Linear(ch_in // reduction, ch_in, bias=False), nn.Sigmoid())
-        self.fc_wight = nn.Sequential(nn.Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
-                                      nn.Linear(ch_in // reduction, 1, bias=False), nn.Sigmoid())
+        self.fc = nn.Sequential(Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
+                                Linear(ch_in // reduction, ch_in, bias=False), nn.Sigmoid())
+        self.fc_wight = nn.Sequential(Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
+                                      Linear(ch_in // reduction, 1, bias=False), nn.Sigmoid())
 
     def _gate(self, x):
         y = x.mean((2, 3))
@@ -463,14 +494,14 @@ class SAM(nn.Module):
 class _ChannelAttention(nn.Module):  # cod.py:371-387; constructed (cod.py:703), never called
     def __init__(self, in_planes):
         super().__init__()
-        self.fc1 = nn.Conv2d(in_planes, in_planes // 16, 1, bias=False)
-        self.fc2 = nn.Conv2d(in_planes // 16, in_planes, 1, bias=False)
+        self.fc1 = Conv2d(in_planes, in_planes // 16, 1, bias=False)
+        self.fc2 = Conv2d(in_planes // 16, in_planes, 1, bias=False)
 
 
 class _SpatialAttention(nn.Module):  # cod.py:390-405; constructed (cod.py:704), never called
     def __init__(self):
         super().__init__()
-        self.conv1 = nn.Conv2d(2, 1, 7, padding=3, bias=False)
+        self.conv1 = Conv2d(2, 1, 7, padding=3, bias=False)
 
 
 def _up(x, scale, align):
@@ -496,8 +527,8 @@ class Hitnet(nn.Module):
         self.ca = _ChannelAttention(64)
         self.sa = _SpatialAttention()
         self.SAM = SAM()
-        self.out_SAM = nn.Conv2d(channel, 1, 1)
-        self.out_CFM = nn.Conv2d(channel, 1, 1)
+        self.out_SAM = Conv2d(channel, 1, 1)
+        self.out_CFM = Conv2d(channel, 1, 1)
         mk = lambda ch: nn.Sequential(*[CAB(ch, kernel_size, reduction, bias=bias, act=act) for _ in range(2)])
         self.decoder_level4 = mk(n_feat)
         self.decoder_level3 = mk(n_feat + scale_unetfeats)

@@ -32,7 +32,7 @@ def build_optimizer(model: torch.nn.Module, lr: float = 5e-4, weight_decay: floa
     groups: Dict[float, list] = {}
     seen = set()
     for name, p in model.named_parameters(remove_duplicate=False):
-        if not p.requires_grad or id(p) in seen:
+        if id(p) in seen:   # bypass_duplicate; masters whose compute runs on a working copy have requires_grad=False
             continue
         seen.add(id(p))
         groups.setdefault(lr_mult_for(name, custom_keys), []).append(p)
