@@ -28,6 +28,8 @@ SIGNATURES = {
     "dgtd_sra_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _fp, _vp, _fp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dgtd_dwconv_fwd": (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_dwconv_bwd_weight": (_i, [_vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_dwconv_pack": (_i, [_vp, _vp, _fp, _i, _i, _i, _vp]),
+    "dgtd_dwconv_unpack_grads": (_i, [_fp, _vp, _vp, _i, _i, _i, _vp]),
     "dgtd_diffuser_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuser_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),

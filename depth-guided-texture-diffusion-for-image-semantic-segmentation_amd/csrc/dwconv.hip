@@ -172,6 +172,32 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   }
 }
 
+// weights [C, K*K] (Conv2d layout, dtype T) + bias [C] -> packed fp32 [ wt (K*K x C) | wt spatially flipped | bias ]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ w, const T* __restrict__ bias,
+                                                          float* __restrict__ packed, int C, int KK) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // i = t * C + c
+  if (i < KK * C) {
+    const int t = i / C, c = i % C;
+    const float v = (float)w[(size_t)c * KK + t];
+    packed[i] = v;
+    packed[(size_t)KK * C + (size_t)(KK - 1 - t) * C + c] = v;
+  }
+  if (i < C) packed[(size_t)2 * KK * C + i] = bias ? (float)bias[i] : 0.f;
+}
+
+// grads fp32 [ dwt (K*K x C) | db (C) ] -> dweight [C, K*K] and dbias [C] in dtype T
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_unpack_kernel(const float* __restrict__ g, T* __restrict__ dw,
+                                                            T* __restrict__ db, int C, int KK) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // i = c * KK + t
+  if (i < KK * C) {
+    const int c = i / KK, t = i % KK;
+    dw[i] = (T)g[(size_t)t * C + c];
+  }
+  if (db && i < C) db[i] = (T)g[(size_t)KK * C + i];
+}
+
 template <typename T, int V, int K, int TX>
 int fwd_launch(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C,
                int mode, hipStream_t s) {
@@ -220,4 +246,24 @@ extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t
   if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<bf16_t, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
   if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<float, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
   DGTD_FAIL(2, "dwconv_bwd_weight: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, int C, int K, dgtd_dtype wdt, dgtd_stream s) {
+  DGTD_REQUIRE(C > 0 && (K == 3 || K == 7), "dwconv_pack: bad sizes C=%d K=%d", C, K);
+  const int KK = K * K, grid = (int)cdiv((int64_t)KK * C, 256);
+  if (wdt == DGTD_BF16) hipLaunchKernelGGL(dwconv_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)w, (const bf16_t*)bias, packed, C, KK);
+  else if (wdt == DGTD_F32) hipLaunchKernelGGL(dwconv_pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)w, (const float*)bias, packed, C, KK);
+  else DGTD_FAIL(2, "dwconv_pack: bad dtype %d", (int)wdt);
+  DGTD_CHECK_LAUNCH("dwconv_pack");
+  return 0;
+}
+
+extern "C" int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int K, dgtd_dtype wdt, dgtd_stream s) {
+  DGTD_REQUIRE(C > 0 && (K == 3 || K == 7), "dwconv_unpack_grads: bad sizes C=%d K=%d", C, K);
+  const int KK = K * K, grid = (int)cdiv((int64_t)KK * C, 256);
+  if (wdt == DGTD_BF16) hipLaunchKernelGGL(dwconv_unpack_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, grads, (bf16_t*)dw, (bf16_t*)db, C, KK);
+  else if (wdt == DGTD_F32) hipLaunchKernelGGL(dwconv_unpack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, grads, (float*)dw, (float*)db, C, KK);
+  else DGTD_FAIL(2, "dwconv_unpack_grads: bad dtype %d", (int)wdt);
+  DGTD_CHECK_LAUNCH("dwconv_unpack_grads");
+  return 0;
 }

@@ -107,41 +107,47 @@ class GradReducer:
 
     # ------------------------------------------------------------------ construction
     def _seal(self, items, castable) -> None:
-        p0 = items[0][1]
-        total = sum(p.numel() for _, p in items)
-        flat = torch.zeros(total, dtype=torch.float32, device=p0.device)
-        masters, leaves, gviews, w_masters, w_leaves = [], [], [], [], []
-        n_work = sum(p.numel() for _, p in items if id(p) in castable)
-        wflat = torch.zeros(n_work, dtype=self.working_dtype, device=p0.device) if n_work else None
-        off = woff = 0
-        for _, p in items:
-            gv = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-            p.grad = gv                      # master .grad = view of the flat fp32 bucket (what the optimizer reads)
-            masters.append(p)
-            gviews.append(gv)
-            if id(p) in castable:
-                m, attr = castable[id(p)]
-                leaf = wflat[woff:woff + p.numel()].view_as(p)
-                woff += p.numel()
-                leaf.requires_grad_(True)    # a leaf: its base buffer does not require grad
-                object.__setattr__(m, attr, leaf)
-                p.requires_grad_(False)      # the master no longer takes part in autograd
-                w_masters.append(p)
-                w_leaves.append(leaf)
-                leaves.append(leaf)
-            else:
-                leaves.append(p)
-        self.buckets.append({"flat": flat, "masters": masters, "leaves": leaves, "gviews": gviews, "w_masters": w_masters,
-                             "w_leaves": w_leaves, "pending": len(items), "n": len(items), "done": False})
+        """Flat layout of a bucket: [ castable parameters | the rest ].  The castable masters are re-homed into one
+        flat fp32 buffer (``p.data`` becomes a view), so master -> working copy is ONE cast kernel."""
+        dev = items[0][1].device
+        work = [(n, p) for n, p in items if id(p) in castable]
+        rest = [(n, p) for n, p in items if id(p) not in castable]
+        n_work, n_rest = sum(p.numel() for _, p in work), sum(p.numel() for _, p in rest)
+        flat = torch.zeros(n_work + n_rest, dtype=torch.float32, device=dev)          # fp32 gradients
+        mflat = torch.empty(n_work, dtype=torch.float32, device=dev) if n_work else None  # fp32 masters (castable part)
+        wflat = torch.empty(n_work, dtype=self.working_dtype, device=dev) if n_work else None
+        masters, leaves, gviews = [], [], []
+        off = 0
+        with torch.no_grad():
+            for _, p in work + rest:
+                n = p.numel()
+                gv = flat[off:off + n].view_as(p)
+                p.grad = gv                      # master .grad = view of the flat fp32 bucket (what the optimizer reads)
+                masters.append(p)
+                gviews.append(gv)
+                if id(p) in castable:
+                    m, attr = castable[id(p)]
+                    mflat[off:off + n].copy_(p.data.reshape(-1))
+                    p.data = mflat[off:off + n].view_as(p)
+                    leaf = wflat[off:off + n].view_as(p)
+                    leaf.requires_grad_(True)    # a leaf: its base buffer does not require grad
+                    object.__setattr__(m, attr, leaf)
+                    p.requires_grad_(False)      # the master no longer takes part in autograd
+                    leaves.append(leaf)
+                else:
+                    leaves.append(p)
+                off += n
+        self.buckets.append({"flat": flat, "mflat": mflat, "wflat": wflat, "n_work": n_work, "k_work": len(work),
+                             "masters": masters, "leaves": leaves, "gviews": gviews,
+                             "pending": len(items), "n": len(items), "done": False})
 
     # ------------------------------------------------------------------ per step
     @torch.no_grad()
     def refresh_working(self) -> None:
-        """master fp32 -> working copy: one multi-tensor cast per bucket (call after optimizer.step())."""
+        """master fp32 -> working copy: ONE cast kernel per bucket (call after optimizer.step())."""
         for b in self.buckets:
-            if b["w_leaves"]:
-                torch._foreach_copy_(b["w_leaves"], b["w_masters"])
+            if b["wflat"] is not None:
+                b["wflat"].copy_(b["mflat"])
 
     def zero_grad(self) -> None:
         """Replaces optimizer.zero_grad(): leaves get .grad = None so autograd hands gradients over without an
@@ -161,17 +167,27 @@ class GradReducer:
 
     @torch.no_grad()
     def _gather(self, bucket) -> None:
-        """leaf gradients (any dtype) -> flat fp32 bucket with one multi-tensor copy; restore master .grad views."""
-        grads, views = [], []
-        for leaf, gv in zip(bucket["leaves"], bucket["gviews"]):
-            if leaf.grad is None:
-                gv.zero_()              # parameter unused this step
+        """Leaf gradients -> flat fp32 bucket: one batched concat per dtype segment (+ one cast for the
+        low-precision segment) instead of a copy kernel per parameter; then restore the master .grad views."""
+        flat, k, nw = bucket["flat"], bucket["k_work"], bucket["n_work"]
+        leaves, gviews = bucket["leaves"], bucket["gviews"]
+
+        def seg(lo, hi, out):
+            if lo == hi:
+                return
+            gs = [l.grad for l in leaves[lo:hi]]
+            if any(g is None for g in gs):   # a parameter unused this step: fall back to per-tensor copies
+                for g, gv in zip(gs, gviews[lo:hi]):
+                    gv.zero_() if g is None else gv.copy_(g)
+                return
+            if gs[0].dtype == out.dtype:
+                torch.cat([g.reshape(-1) for g in gs], out=out)
             else:
-                grads.append(leaf.grad)
-                views.append(gv)
-        if grads:
-            torch._foreach_copy_(views, grads)
-        for p, leaf, gv in zip(bucket["masters"], bucket["leaves"], bucket["gviews"]):
+                out.copy_(torch.cat([g.reshape(-1) for g in gs]))
+
+        seg(0, k, flat[:nw])
+        seg(k, len(leaves), flat[nw:])
+        for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
             leaf.grad = None            # free the per-leaf gradient
             p.grad = gv
         bucket["done"] = True

@@ -7,10 +7,10 @@ from torch.autograd.function import once_differentiable
 from .. import _lib as L
 
 
-def _launch_fwd(x, wt, bias, aux, mode, K):
+def _launch_fwd(x, wt_ptr, bias_ptr, aux, mode, K):
     B, H, W, C = x.shape
     y = torch.empty_like(x)
-    L.call("dgtd_dwconv_fwd", L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(aux), L.ptr(y), B, H, W, C, K, mode,
+    L.call("dgtd_dwconv_fwd", L.ptr(x), wt_ptr, bias_ptr, L.ptr(aux), L.ptr(y), B, H, W, C, K, mode,
            L.dtype_code(x), L.stream_ptr(), algo=("hbm", (3 if mode == 2 else 2) * x.element_size() * x.numel()),
            key=f"dgtd_dwconv_fwd[k{K},mode{mode},{H}x{W}x{C}]")
     return y
@@ -22,34 +22,42 @@ class _DwConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gelu):
-        L.check_cuda(x)
+        L.check_cuda(x, weight)
         C, K = weight.shape[0], weight.shape[-1]
-        assert x.shape[-1] == C and weight.shape[1] == 1
-        wt = weight.detach().float().reshape(C, K * K).t().contiguous()   # [K*K, C]: lanes along C read contiguous taps
-        b32 = bias.detach().float().contiguous() if bias is not None else None
-        y = _launch_fwd(x, wt, b32, None, 1 if gelu else 0, K)
-        ctx.save_for_backward(x, wt, b32 if b32 is not None else torch.empty(0, device=x.device))
-        ctx.meta = (gelu, K, bias is not None, weight.shape)
+        KK = K * K
+        assert x.shape[-1] == C and weight.shape[1] == 1 and (bias is None or bias.dtype == weight.dtype)
+        packed = torch.empty((2 * KK + 1) * C, dtype=torch.float32, device=x.device)   # { w_t | w_t flipped | bias }
+        L.call("dgtd_dwconv_pack", L.ptr(weight), L.ptr(bias), L.ptr(packed), C, K, L.dtype_code(weight), L.stream_ptr())
+        base = packed.data_ptr()
+        y = _launch_fwd(x, base, base + 8 * KK * C if bias is not None else None, None, 1 if gelu else 0, K)
+        ctx.save_for_backward(x, packed)
+        ctx.meta = (gelu, K, bias is not None, weight.shape, weight.dtype)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, wt, b32 = ctx.saved_tensors
-        gelu, K, has_bias, wshape = ctx.meta
+        x, packed = ctx.saved_tensors
+        gelu, K, has_bias, wshape, wdtype = ctx.meta
         B, H, W, C = x.shape
+        KK = K * K
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        bias = b32 if has_bias else None
-        du = _launch_fwd(x, wt, bias, dy, 2, K) if gelu else dy           # through the GELU: recompute the pre-activation
-        dx = _launch_fwd(du, wt.flip(0).contiguous(), None, None, 0, K)    # bwd-data = same kernel, flipped filter
-        dwt = torch.zeros_like(wt)
-        db = torch.zeros(C, dtype=torch.float32, device=x.device) if has_bias else None
-        L.call("dgtd_dwconv_bwd_weight", L.ptr(x), L.ptr(du), L.ptr(dwt), L.ptr(db), B, H, W, C, K, L.dtype_code(x),
-               L.stream_ptr(), algo=("hbm", 2 * x.element_size() * x.numel()), key=f"dgtd_dwconv_bwd_weight[k{K},{H}x{W}x{C}]")
-        return dx, dwt.t().reshape(wshape), db, None
+        base = packed.data_ptr()
+        bias_ptr = base + 8 * KK * C if has_bias else None
+        du = _launch_fwd(x, base, bias_ptr, dy, 2, K) if gelu else dy      # through the GELU: recompute the pre-activation
+        dx = _launch_fwd(du, base + 4 * KK * C, None, None, 0, K)          # bwd-data = same kernel, flipped filter
+        grads = torch.zeros((KK + 1) * C, dtype=torch.float32, device=x.device)   # { dw_t | db }, atomically accumulated
+        gb = grads.data_ptr()
+        L.call("dgtd_dwconv_bwd_weight", L.ptr(x), L.ptr(du), gb, gb + 4 * KK * C if has_bias else None, B, H, W, C, K,
+               L.dtype_code(x), L.stream_ptr(), algo=("hbm", 2 * x.element_size() * x.numel()),
+               key=f"dgtd_dwconv_bwd_weight[k{K},{H}x{W}x{C}]")
+        dw = torch.empty(wshape, dtype=wdtype, device=x.device)
+        db = torch.empty(C, dtype=wdtype, device=x.device) if has_bias else None
+        L.call("dgtd_dwconv_unpack_grads", gb, L.ptr(dw), L.ptr(db), C, K, L.dtype_code(dw), L.stream_ptr())
+        return dx, dw, db, None
 
 
 def dwconv_nhwc(x: torch.Tensor, weight: torch.Tensor, bias, gelu: bool = False) -> torch.Tensor:
-    return _DwConvFn.apply(x.contiguous(), weight, bias, gelu)
+    return _DwConvFn.apply(x.contiguous(), weight.contiguous(), bias, gelu)

@@ -68,6 +68,11 @@ int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void
  * Backward w.r.t. x = mode 0 applied to the gradient with the spatially flipped filter.            */
 int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y,
                     int B, int H, int W, int C, int K, int mode, dgtd_dtype dt, dgtd_stream s);
+/* Conv2d-layout parameters -> kernel layout, one launch: w [C,1,K,K] and bias [C] (dtype wdt; bias may be NULL)
+ * -> packed fp32 [(2*K*K + 1) * C] = { w_t | w_t spatially flipped (for the backward w.r.t. x) | bias }.      */
+int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, int C, int K, dgtd_dtype wdt, dgtd_stream s);
+/* grads fp32 [(K*K + 1) * C] = { dw_t | db } -> dw [C,1,K,K], db [C] in dtype wdt (db may be NULL).           */
+int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int K, dgtd_dtype wdt, dgtd_stream s);
 /* dw_t fp32 [K*K, C] and db fp32 [C] (db may be NULL) must be ZEROED by the caller; C % 128 == 0.   */
 int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t, float* db,
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
