@@ -30,6 +30,10 @@ SIGNATURES = {
     "dgtd_dwconv_bwd_weight": (_i, [_vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_dwconv_pack": (_i, [_vp, _vp, _fp, _i, _i, _i, _vp]),
     "dgtd_dwconv_unpack_grads": (_i, [_fp, _vp, _vp, _i, _i, _i, _vp]),
+    "dgtd_scale_residual_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _i64, _i, _i64, _i, _vp]),
+    "dgtd_colsum_workspace": (_i64, [_i]),
+    "dgtd_scale_residual_bwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _vp, _i64, _i, _i64, _i, _vp]),
+    "dgtd_colsum": (_i, [_vp, _fp, _vp, _i64, _i, _i, _vp]),
     "dgtd_diffuser_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuser_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),

@@ -1,0 +1,177 @@
+// elementwise.hip — fused residual epilogues and column sums on token-major [rows, C] tensors.
+//   scale_residual: out = x + s[b] * gamma[c] * y      (convnext_Block tail: gamma * x, DropPath, residual, twig/model/cod.py:1112-1116;
+//                                                       Block residuals x + DropPath(.) cod.py:958-959; s = per-sample stochastic-depth scale)
+//   its backward:   dy = s[b] * gamma[c] * g ,  dgamma[c] = sum_r s[b] * g * y      (dx = g is the identity, no kernel)
+//   colsum:         out[c] = sum_r x[r, c]             (bias gradients of the Linear layers: one pass instead of a generic reduce)
+// HBM-bound: fwd 3e*rows*C, bwd 3e*rows*C, colsum e*rows*C.  Lanes run along C in 16-byte chunks; column partials stay in
+// registers across the row loop, meet in LDS per workgroup, and a deterministic second stage sums the per-workgroup rows.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_MAX_BLOCKS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                 const float* __restrict__ s, const float* __restrict__ gamma,
+                                                                 T* __restrict__ out, int64_t rows, int C, int64_t rows_per_sample) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const int64_t total = rows * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int64_t r = i / CV;
+    const float sb = s ? s[r / rows_per_sample] : 1.f;
+    VT xv = *reinterpret_cast<const VT*>(x + i * V);
+    VT yv = *reinterpret_cast<const VT*>(y + i * V);
+    VT o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float g = gamma ? gamma[cv * V + j] : 1.f;
+      o[j] = (T)((float)xv[j] + sb * g * (float)yv[j]);
+    }
+    *reinterpret_cast<VT*>(out + i * V) = o;
+  }
+}
+
+// MODE 0: colsum of g.   MODE 1: dy = s*gamma*g and partial dgamma = sum s*g*y.   MODE 2: dy = s*g only (no gamma, no sums).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ s,
+                                                     const float* __restrict__ gamma, T* __restrict__ dy, float* __restrict__ ws,
+                                                     int64_t rows, int C, int64_t rows_per_sample) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ float red[];                 // [RG][CVB * V]
+  const int CV = C / V;
+  const int CVB = min(CV - (int)blockIdx.y * 256, 256);       // chunk-columns handled by this workgroup
+  const int RG = 256 / CVB;                                   // row groups inside the workgroup (CVB is a power of two or <= 256)
+  const int tid = threadIdx.x;
+  const int cvl = tid % CVB, rg = tid / CVB;
+  const int cv = blockIdx.y * 256 + cvl;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  float gm[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) gm[j] = (MODE == 1 && gamma) ? gamma[cv * V + j] : 1.f;
+  if (rg < RG) {
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < rows; r += (int64_t)gridDim.x * RG) {
+      const size_t off = (size_t)r * C + (size_t)cv * V;
+      VT gv = *reinterpret_cast<const VT*>(g + off);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += (float)gv[j];
+      } else {
+        const float sb = s ? s[r / rows_per_sample] : 1.f;
+        VT o;
+        if (MODE == 1) {
+          VT yv = *reinterpret_cast<const VT*>(y + off);
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float gg = sb * (float)gv[j];
+            acc[j] += gg * (float)yv[j];
+            o[j] = (T)(gg * gm[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = (T)(sb * (float)gv[j]);
+        }
+        *reinterpret_cast<VT*>(dy + off) = o;
+      }
+    }
+  }
+  if (MODE == 2) return;
+  if (rg < RG)
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[(rg * CVB + cvl) * V + j] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < CVB * V; i += 256) {
+    float t = 0.f;
+    for (int k = 0; k < RG; ++k) t += red[k * CVB * V + i];
+    ws[(size_t)blockIdx.x * C + (size_t)blockIdx.y * 256 * V + i] = t;
+  }
+}
+
+// ws [nblocks][C] -> out[C]; one workgroup per 64 columns, 4 waves over the rows, fixed summation order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < C) {
+    const float* p = ws + col;
+    int b = wave;
+    for (; b + 28 < nblocks; b += 32) {
+      const float v0 = p[(size_t)b * C], v1 = p[(size_t)(b + 4) * C], v2 = p[(size_t)(b + 8) * C], v3 = p[(size_t)(b + 12) * C];
+      const float v4 = p[(size_t)(b + 16) * C], v5 = p[(size_t)(b + 20) * C], v6 = p[(size_t)(b + 24) * C], v7 = p[(size_t)(b + 28) * C];
+      s0 += ((v0 + v1) + (v2 + v3));
+      s1 += ((v4 + v5) + (v6 + v7));
+    }
+    for (; b < nblocks; b += 4) s0 += p[(size_t)b * C];
+  }
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && col < C) out[col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+template <typename T>
+int check_c(int C, const char* who) {
+  constexpr int V = Vec16<T>::N;
+  DGTD_REQUIRE(C % V == 0, "%s: C=%d must be a multiple of %d", who, C, V);
+  return 0;
+}
+
+template <typename T, int MODE>
+int colsum_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* out, void* ws, int64_t rows,
+                  int C, int64_t rps, hipStream_t st, const char* who) {
+  if (int rc = check_c<T>(C, who)) return rc;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V, ncb = (int)cdiv(CV, 256);
+  const int cvb0 = std::min(CV, 256), rg = 256 / cvb0;
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, (int64_t)rg * 4), EW_MAX_BLOCKS));
+  const size_t lds = (size_t)256 * V * sizeof(float);
+  hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
+  DGTD_CHECK_LAUNCH(who);
+  if (MODE != 2) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, out, gx, C);
+    DGTD_CHECK_LAUNCH(who);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out, int64_t rows,
+                                       int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0, "scale_residual_fwd: bad sizes");
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(C % V == 0, "scale_residual_fwd: C=%d must be a multiple of %d", C, V);
+  const int grid = (int)std::min<int64_t>(cdiv(rows * (C / V), 256), 256 * 16);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(scale_residual_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const bf16_t*)x, (const bf16_t*)y, s, gamma, (bf16_t*)out, rows, C, rows_per_sample);
+  else if (dt == DGTD_F32) hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const float*)x, (const float*)y, s, gamma, (float*)out, rows, C, rows_per_sample);
+  else DGTD_FAIL(2, "scale_residual_fwd: bad dtype %d", (int)dt);
+  DGTD_CHECK_LAUNCH("scale_residual_fwd");
+  return 0;
+}
+
+extern "C" int64_t dgtd_colsum_workspace(int C) { return (int64_t)EW_MAX_BLOCKS * C * sizeof(float); }
+
+extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
+                                       void* workspace, int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0, "scale_residual_bwd: bad sizes");
+  DGTD_REQUIRE((gamma == nullptr) == (dgamma == nullptr), "scale_residual_bwd: gamma and dgamma go together");
+  hipStream_t h = (hipStream_t)st;
+  if (dt == DGTD_BF16) return gamma ? colsum_launch<bf16_t, 1>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd")
+                                    : colsum_launch<bf16_t, 2>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd");
+  if (dt == DGTD_F32) return gamma ? colsum_launch<float, 1>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd")
+                                   : colsum_launch<float, 2>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd");
+  DGTD_FAIL(2, "scale_residual_bwd: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_colsum(const void* x, float* out, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0, "colsum: bad sizes");
+  if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum");
+  if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum");
+  DGTD_FAIL(2, "colsum: bad dtype %d", (int)dt);
+}

@@ -27,12 +27,23 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
-    def forward(self, x):
+        self.index, self.plan = -1, None   # set by cod: all masks of a step are drawn in one launch (see cod._run)
+
+    def scale(self, batch: int, device):
+        """Per-sample scale [B] fp32 (0 or 1/keep) for this step, or None when the layer is the identity."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
+        plan = self.plan
+        if plan is not None and plan.get("masks") is not None and plan["masks"].shape[1] == batch:
+            return plan["masks"][self.index]
         keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
-        return x * mask.div_(keep)
+        return torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+    def forward(self, x):
+        s = self.scale(x.shape[0], x.device)
+        if s is None:
+            return x
+        return x * s.to(x.dtype).view((x.shape[0],) + (1,) * (x.ndim - 1))
 
 
 class Linear(nn.Linear):
@@ -42,7 +53,7 @@ class Linear(nn.Linear):
     _b = None
 
     def forward(self, x):
-        return F.linear(x, *wb(self))
+        return ops.linear(x, *wb(self)) if x.is_cuda else F.linear(x, *wb(self))
 
 
 class Conv2d(nn.Conv2d):
@@ -151,7 +162,7 @@ class Attention(nn.Module):
         q = self.q(x)
         if self.sr_ratio > 1:  # k == s conv == patchify + GEMM, stays token-major
             w, b = wb(self.sr)
-            r = F.linear(_patchify(x, H, W, self.sr_ratio), w.flatten(1), b)
+            r = ops.linear(_patchify(x, H, W, self.sr_ratio), w.flatten(1), b)
             r = self.norm(r)
         else:
             r = x
@@ -201,9 +212,12 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
         self.apply(_init_weights)
 
+    def _scale(self, x):
+        return self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
+
     def forward(self, x, H, W):
-        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
-        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+        x = ops.scale_residual(x, self.attn(self.norm1(x), H, W), self._scale(x))   # x + DropPath(attn), one pass
+        return ops.scale_residual(x, self.mlp(self.norm2(x), H, W), self._scale(x))
 
 
 # ------------------------------------------------------------------------------------------------ diffuser
@@ -222,9 +236,8 @@ class convnext_Block(nn.Module):
     def forward_nhwc(self, x):
         y = ops.dwconv_nhwc(x, *wb(self.dwconv))
         y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
-        if self.gamma is not None:
-            y = self.gamma.to(y.dtype) * y
-        return x + self.drop_path(y)
+        s = self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
+        return ops.scale_residual(x, y, s, self.gamma)   # x + DropPath(gamma * y) in one pass
 
     def forward(self, x):  # reference contract: NCHW in, NCHW out
         return self.forward_nhwc(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
@@ -256,13 +269,13 @@ class ShapePropEncoder(nn.Module):
         conv, norm = self.downsample_layers[0]
         t = x.view(B, 3, H // 4, 4, W // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 4) * (W // 4), 48)
         w, b = wb(conv)
-        t = norm(F.linear(t, w.flatten(1), b))
+        t = norm(ops.linear(t, w.flatten(1), b))
         h, w = H // 4, W // 4
         for i in range(4):
             if i > 0:
                 norm, conv = self.downsample_layers[i]
                 cw, cb = wb(conv)
-                t = F.linear(_patchify(norm(t), h, w, 2), cw.flatten(1), cb)
+                t = ops.linear(_patchify(norm(t), h, w, 2), cw.flatten(1), cb)
                 h, w = h // 2, w // 2
             t4 = t.view(B, h, w, -1)
             for blk in self.stages[i]:
@@ -273,7 +286,7 @@ class ShapePropEncoder(nn.Module):
         taps = []
         for (t, h, w), conv in zip(outs, self.convs):  # 1x1 conv == GEMM on tokens, then bilinear to stride 4
             cw, cb = wb(conv)
-            y = _tokens_to_nchw(F.linear(t, cw.flatten(1), cb), h, w)
+            y = _tokens_to_nchw(ops.linear(t, cw.flatten(1), cb), h, w)
             taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
         return self.fusion_conv(torch.cat(taps, dim=1))
 
@@ -559,9 +572,16 @@ class Hitnet(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ losses / top level
-def cal_loss(preds, gts):
+def loss_weight(gts):
+    """cod.py:77: the 31x31 box-filter edge weight.  It depends on the label only, so one evaluation serves all five
+    cal_loss calls of a step (the reference recomputes it five times)."""
+    return 1 + 5 * torch.abs(F.avg_pool2d(gts, kernel_size=31, stride=1, padding=15) - gts)
+
+
+def cal_loss(preds, gts, weit=None):
     """cod.py:76-85."""
-    weit = 1 + 5 * torch.abs(F.avg_pool2d(gts, kernel_size=31, stride=1, padding=15) - gts)
+    if weit is None:
+        weit = loss_weight(gts)
     wbce = F.binary_cross_entropy_with_logits(preds, gts, reduction="none")
     wbce = (weit * wbce).sum(dim=(2, 3)) / weit.sum(dim=(2, 3))
     p = torch.sigmoid(preds)
@@ -601,8 +621,22 @@ class cod(nn.Module):
         self.hitnet = Hitnet(drop_path_rate=drop_path_rate)
         self.batch = 0
         self.compute_dtype = compute_dtype
+        self._dp_plan = {"masks": None}
+        self._dp_layers = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0]
+        for i, m in enumerate(self._dp_layers):
+            m.index, m.plan = i, self._dp_plan
+        self.register_buffer("_dp_keep", torch.tensor([[1.0 - m.drop_prob] for m in self._dp_layers] or [[1.0]]), persistent=False)
+
+    def _draw_drop_path(self, batch: int) -> None:
+        """All stochastic-depth masks of the step in one shot: [n_layers, B] of {0, 1/keep} (cod.py:935, :1102 per layer)."""
+        if self.training and self._dp_layers:
+            keep = self._dp_keep
+            self._dp_plan["masks"] = (torch.rand(keep.shape[0], batch, device=keep.device) < keep).float() / keep
+        else:
+            self._dp_plan["masks"] = None
 
     def _run(self, input, depth):
+        self._draw_drop_path(input.shape[0])
         if self.compute_dtype == torch.bfloat16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return self.hitnet(input, depth)
@@ -615,8 +649,9 @@ class cod(nn.Module):
         embedding1, P1, P2 = self._run(input, depth)
         if mode == "loss":
             label = label.float()
-            losses = [cal_loss(p, label) for p in P1]
-            loss = cal_loss(P2, label)
+            weit = loss_weight(label)
+            losses = [cal_loss(p, label, weit) for p in P1]
+            loss = cal_loss(P2, label, weit)
             for it in range(len(P1)):
                 loss = loss + (0.2 * it) * losses[it]
             with torch.no_grad():

@@ -5,3 +5,4 @@ from .layernorm import layer_norm  # noqa: F401
 from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401
 from .dwconv import dwconv_nhwc  # noqa: F401
+from .elementwise import colsum, linear, scale_residual  # noqa: F401

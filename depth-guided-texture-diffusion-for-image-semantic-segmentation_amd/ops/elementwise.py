@@ -1,0 +1,116 @@
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Persistent per-device scratch for the two-stage column sums (stream-ordered reuse on the compute stream)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a [rows, C] matrix (bias gradients)."""
+    L.check_cuda(x2d)
+    rows, C = x2d.shape
+    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = _workspace(L.load().dgtd_colsum_workspace(C), x2d.device)
+    L.call("dgtd_colsum", L.ptr(x2d), L.ptr(out), L.ptr(ws), rows, C, L.dtype_code(x2d), L.stream_ptr(),
+           algo=("hbm", x2d.element_size() * x2d.numel()), key=f"dgtd_colsum[rows={rows},C={C}]")
+    return out
+
+
+class _ScaleResidualFn(Function):
+    """out = x + s[b] * gamma[c] * y on [B, ..., C] (cod.py:1112-1116, :958-959); s = per-sample DropPath scale or None."""
+
+    @staticmethod
+    def forward(ctx, x, y, s, gamma):
+        L.check_cuda(x, y)
+        B, C = x.shape[0], x.shape[-1]
+        rows = x.numel() // C
+        g32 = gamma.detach().float().contiguous() if gamma is not None else None
+        out = torch.empty_like(x)
+        L.call("dgtd_scale_residual_fwd", L.ptr(x), L.ptr(y), L.ptr(s), L.ptr(g32), L.ptr(out), rows, C, rows // B,
+               L.dtype_code(x), L.stream_ptr(), algo=("hbm", 3 * x.element_size() * x.numel()),
+               key=f"dgtd_scale_residual_fwd[rows={rows},C={C}]")
+        ctx.save_for_backward(y, s if s is not None else torch.empty(0, device=x.device),
+                              g32 if g32 is not None else torch.empty(0, device=x.device))
+        ctx.meta = (s is not None, gamma is not None, gamma.dtype if gamma is not None else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, s, g32 = ctx.saved_tensors
+        has_s, has_g, gdtype = ctx.meta
+        g = g.contiguous()
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        if not has_s and not has_g:
+            return g, g, None, None
+        B, C = y.shape[0], y.shape[-1]
+        rows = y.numel() // C
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(C, dtype=torch.float32, device=y.device) if has_g else None
+        ws = _workspace(L.load().dgtd_colsum_workspace(C), y.device) if has_g else None
+        L.call("dgtd_scale_residual_bwd", L.ptr(g), L.ptr(y), L.ptr(s) if has_s else None, L.ptr(g32) if has_g else None,
+               L.ptr(dy), L.ptr(dgamma), L.ptr(ws), rows, C, rows // B, L.dtype_code(y), L.stream_ptr(),
+               algo=("hbm", (3 if has_g else 2) * y.element_size() * y.numel()), key=f"dgtd_scale_residual_bwd[rows={rows},C={C}]")
+        return g, dy, None, (dgamma.to(gdtype) if has_g else None)
+
+
+def scale_residual(x, y, s=None, gamma=None):
+    if s is None and gamma is None:
+        return x + y
+    if y.dtype != x.dtype:
+        y = y.to(x.dtype)
+    return _ScaleResidualFn.apply(x.contiguous(), y.contiguous(), s, gamma)
+
+
+class _LinearFn(Function):
+    """y = x W^T + b with library GEMMs (hipBLASLt) and the bias gradient as ONE column-sum pass (dgtd_colsum) instead of
+    a generic strided reduction per layer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        with torch.autocast("cuda", enabled=False):
+            x2 = x.reshape(-1, x.shape[-1])
+            if x2.dtype != dt:
+                x2 = x2.to(dt)
+            wc = w if w.dtype == dt else w.to(dt)
+            if b is not None:
+                out = torch.addmm(b if b.dtype == dt else b.to(dt), x2, wc.t())
+            else:
+                out = x2 @ wc.t()
+        ctx.save_for_backward(x2, wc)
+        ctx.meta = (x.shape, x.dtype, w.dtype, b.dtype if b is not None else None)
+        return out.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, wc = ctx.saved_tensors
+        xshape, xdtype, wdtype, bdtype = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        dy2 = dy2.contiguous()
+        dx = (dy2 @ wc).view(xshape) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x2
+        db = colsum(dy2).to(bdtype) if bdtype is not None else None
+        return dx, (dw if dw.dtype == wdtype else dw.to(wdtype)), db
+
+
+def linear(x, w, b=None):
+    return _LinearFn.apply(x, w, b)

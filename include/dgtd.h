@@ -77,6 +77,20 @@ int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int 
 int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t, float* db,
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Fused residual epilogue and column sums on [rows, C] token matrices -------------------------
+ * out = x + s[b] * gamma[c] * y : convnext_Block tail (gamma*x, DropPath, residual; twig/model/cod.py:1112-1116) and the
+ * Block residuals x + DropPath(.) (cod.py:958-959).  s fp32 [B] = per-sample stochastic-depth scale (0 or 1/keep) or NULL;
+ * gamma fp32 [C] or NULL; row r belongs to sample r / rows_per_sample.                                                */
+int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out,
+                            int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st);
+int64_t dgtd_colsum_workspace(int C);
+/* dy = s*gamma*g (overwritten); dgamma[c] = sum_r s*g*y (overwritten; NULL iff gamma is NULL).  d(out)/dx is the identity. */
+int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy,
+                            float* dgamma, void* workspace, int64_t rows, int C, int64_t rows_per_sample,
+                            dgtd_dtype dt, dgtd_stream st);
+/* out fp32 [C] = column sums of x [rows, C]: the bias gradient of nn.Linear (cod.py:829,832,872-875,1097,1099).        */
+int dgtd_colsum(const void* x, float* out, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st);
+
 /* ---- Texture diffuser front end (fp32) -------------------------------------------------------
  * replaces twig/model/cod.py:1295-1298 (nearest 12x12 sample of the FFT high-pass image, 1x1 conv 3->1176,
  * sigmoid; depth 1x1 conv 1->24 + bilinear to 12x12) and MessagePassing.forward cod.py:1193-1205

@@ -24,6 +24,15 @@ def _toy():
 
 
 def _worker(rank, world, port, working, q):
+    try:
+        _worker_body(rank, world, port, working, q)
+    except Exception:  # surface the rank's traceback in the parent instead of a bare exit code
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, working, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import dgtd
     dgtd.dist.init_process_group("gloo")
@@ -60,7 +69,9 @@ def test_grad_reducer_matches_large_batch(working):
     procs = [ctx.Process(target=_worker, args=(r, world, port, working, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(world))
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for r, v in got.items():
+        assert not isinstance(v, str), f"rank {r}: {v}"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -130,3 +130,54 @@ def test_diffuser_front_end_vs_oracle(dgtd, S):
     got = torch.autograd.grad(out, dev, gout.cuda())
     for n, a, b in zip(names, got, want):
         torch.testing.assert_close(a.cpu(), b, atol=2e-4 * max(1.0, b.abs().max().item()), rtol=2e-3, msg=lambda m, n=n: f"{n}: {m}")
+
+
+# ---------------------------------------------------------------------------------------------- fused epilogues
+@pytest.mark.parametrize("C", [64, 320, 1024, 2048])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_s,with_g", [(True, True), (True, False), (False, True)])
+def test_scale_residual_fwd_bwd(dgtd, C, dtype, with_s, with_g):
+    B, N = 3, 173
+    x, y, g = (_rand(B, N, C, seed=i, dtype=dtype) for i in (1, 2, 3))
+    s = torch.tensor([0.0, 1.25, 1.25], device="cuda") if with_s else None
+    gamma = (1 + 0.1 * _rand(C, seed=4)).requires_grad_() if with_g else None
+    xr, yr = x.float().requires_grad_(), y.float().requires_grad_()
+    t = yr * (gamma if with_g else 1.0)
+    if with_s:
+        t = t * s.view(B, 1, 1)
+    ref = xr + t
+    wants = torch.autograd.grad(ref, [xr, yr] + ([gamma] if with_g else []), g.float())
+    xs, ys = x.clone().requires_grad_(), y.clone().requires_grad_()
+    out = dgtd.ops.scale_residual(xs, ys, s, gamma)
+    gots = torch.autograd.grad(out, [xs, ys] + ([gamma] if with_g else []), g)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(gots[0].float(), wants[0], atol=tol, rtol=tol)
+    torch.testing.assert_close(gots[1].float(), wants[1], atol=tol, rtol=tol)
+    if with_g:
+        torch.testing.assert_close(gots[2], wants[2], atol=(2e-4 if dtype == torch.float32 else 0.3), rtol=(1e-4 if dtype == torch.float32 else 3e-2))
+
+
+@pytest.mark.parametrize("rows,K,N", [(1000, 64, 512), (77, 320, 1280), (4, 2048, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_with_colsum_bias_grad(dgtd, rows, K, N, dtype):
+    x = _rand(2, rows, K, seed=1, dtype=dtype)
+    w = _rand(N, K, seed=2, dtype=dtype, scale=K ** -0.5)
+    b = _rand(N, seed=3, dtype=dtype, scale=0.1)
+    dy = _rand(2, rows, N, seed=4, dtype=dtype)
+    xr, wr, br = (t.float().requires_grad_() for t in (x, w, b))
+    ref = F.linear(xr, wr, br)
+    wants = torch.autograd.grad(ref, (xr, wr, br), dy.float())
+    xs, ws, bs = (t.clone().requires_grad_() for t in (x, w, b))
+    out = dgtd.ops.linear(xs, ws, bs)
+    gots = torch.autograd.grad(out, (xs, ws, bs), dy)
+    if dtype == torch.float32:
+        tols = [(2e-4, 2e-4)] * 4  # library fp32 GEMM vs fp32 GEMM: different blocking only
+    else:
+        tols = [(5e-2, 5e-2)] * 4
+    torch.testing.assert_close(out.float(), ref, atol=tols[0][0], rtol=tols[0][1])
+    torch.testing.assert_close(gots[0].float(), wants[0], atol=tols[1][0], rtol=tols[1][1])
+    assert (gots[1].float() - wants[1]).norm() / wants[1].norm() < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert (gots[2].float() - wants[2]).norm() / wants[2].norm() < (1e-5 if dtype == torch.float32 else 2e-2)
+    cs = dgtd.ops.colsum(dy.reshape(-1, N))
+    torch.testing.assert_close(cs, dy.float().reshape(-1, N).sum(0), atol=1e-3 if dtype == torch.float32 else 1e-2, rtol=1e-4)
