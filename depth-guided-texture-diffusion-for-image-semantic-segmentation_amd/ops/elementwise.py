@@ -89,13 +89,17 @@ class _LinearFn(Function):
             if x2.dtype != dt:
                 x2 = x2.to(dt)
             wc = w if w.dtype == dt else w.to(dt)
+            # the output is allocated in its final shape and the GEMM writes into a 2-D alias of it, so what autograd sees
+            # is a base tensor (a view created inside a Function may not be modified in place, e.g. by nn.ReLU(inplace=True))
+            out = torch.empty(*x.shape[:-1], w.shape[0], dtype=dt, device=x.device)
+            o2 = out.view(-1, w.shape[0])
             if b is not None:
-                out = torch.addmm(b if b.dtype == dt else b.to(dt), x2, wc.t())
+                torch.addmm(b if b.dtype == dt else b.to(dt), x2, wc.t(), out=o2)
             else:
-                out = x2 @ wc.t()
+                torch.mm(x2, wc.t(), out=o2)
         ctx.save_for_backward(x2, wc)
         ctx.meta = (x.shape, x.dtype, w.dtype, b.dtype if b is not None else None)
-        return out.view(*x.shape[:-1], w.shape[0])
+        return out
 
     @staticmethod
     @once_differentiable
