@@ -98,8 +98,16 @@ def _patchify(x: torch.Tensor, H: int, W: int, k: int) -> torch.Tensor:
 
 
 def _tokens_to_nchw(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """[B, H*W, C] tokens -> logical [B, C, H, W] WITHOUT moving data: the result is a channels_last tensor, which is what
+    MIOpen's NHWC convolution kernels, BatchNorm and the bilinear resamplers consume natively."""
     B, _, Cc = x.shape
     return x.view(B, H, W, Cc).permute(0, 3, 1, 2)
+
+
+def _nchw_to_tokens(x: torch.Tensor) -> torch.Tensor:
+    """logical [B, C, H, W] -> [B, H*W, C]; a free view when x is channels_last, one transpose copy otherwise."""
+    B, Cc, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, H * W, Cc)
 
 
 class LayerNorm(nn.Module):
@@ -134,10 +142,9 @@ class OverlapPatchEmbed(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x):
-        x = self.proj(x)
+        x = self.proj(x.contiguous(memory_format=torch.channels_last))   # no-op when the producer already is channels_last
         H, W = x.shape[-2:]
-        x = x.flatten(2).transpose(1, 2).contiguous()
-        return self.norm(x), H, W
+        return self.norm(_nchw_to_tokens(x)), H, W
 
 
 class Attention(nn.Module):
@@ -374,6 +381,29 @@ class ShapePropDecoder(nn.Module):
     def forward(self, embedding):
         return self.decoder(embedding)
 
+    def forward_tokens(self, embedding, H, W):
+        """== F.interpolate(self.decoder(embedding), (H, W), 'bilinear') as tokens [B, H*W, C] (cod.py:1471), without ever
+        materialising the full-resolution prompt: for an integer power-of-two down-scale s the align_corners=False bilinear
+        sample is the mean of the 2x2 centre pixels, and mean-of-conv3x3 == one 4x4 convolution with stride s whose
+        kernel is the mean of the four shifted 3x3 kernels (zero padding carries over unchanged)."""
+        h = self.decoder[3](self.decoder[2](self.decoder[1](self.decoder[0](embedding))))
+        conv = self.decoder[4]
+        w, b = wb(conv)
+        Hin = h.shape[-2]
+        s_ = Hin // H
+        if s_ == 1:
+            y = F.conv2d(h, w, b, padding=1)
+        elif s_ in (2, 4, 8) and Hin == H * s_ and h.shape[-1] == W * s_:
+            w4 = 0.25 * (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0)))
+            off = s_ // 2 - 2                      # first input row/col of the 4x4 window of output 0
+            if off < 0:
+                y = F.conv2d(h, w4, b, stride=s_, padding=-off)
+            else:
+                y = F.conv2d(h[:, :, off:, off:], w4, b, stride=s_)
+        else:                                      # any other geometry: the literal reference sequence
+            y = F.interpolate(F.conv2d(h, w, b, padding=1), size=(H, W), mode="bilinear", align_corners=False)
+        return _nchw_to_tokens(y)
+
 
 class prompt_decoder(nn.Module):
     """cod.py:1308-1323."""
@@ -385,6 +415,9 @@ class prompt_decoder(nn.Module):
 
     def forward(self, embedding, cross=False):
         return [self.decoder[i](embedding) for i in range(self.depth)]
+
+    def forward_tokens(self, embedding, H, W):
+        return [self.decoder[i].forward_tokens(embedding, H, W) for i in range(self.depth)]
 
 
 class PyramidVisionTransformerImpr(nn.Module):
@@ -419,15 +452,15 @@ class PyramidVisionTransformerImpr(nn.Module):
         B = x.shape[0]
         image = x
         embedding1, embedding3 = self.prompt_encoder(image, depth)
+        embedding3 = embedding3.contiguous(memory_format=torch.channels_last)
         outs = []
         for i in range(4):
             x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
-            prompts = self.prompt_decoder[i](embedding3)
+            prompts = self.prompt_decoder[i].forward_tokens(embedding3, H, W)   # already at (H, W), already tokens
             for j, blk in enumerate(getattr(self, f"block{i + 1}")):
-                p = F.interpolate(prompts[j], size=(H, W), mode="bilinear", align_corners=False)
-                x = blk(x + p.flatten(2).transpose(1, 2), H, W)
+                x = blk(x + prompts[j], H, W)
             x = getattr(self, f"norm{i + 1}")(x)
-            x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            x = _tokens_to_nchw(x, H, W)   # channels_last view: feeds the next patch embed and the Hitnet decoder as is
             outs.append(x)
         return embedding1, outs
 
