@@ -10,6 +10,32 @@ import csv
 import sys
 
 
+def category(n: str) -> str:
+    if n.startswith("Cijk"):
+        return "library GEMM (hipBLASLt)"
+    if any(k in n for k in ("igemm", "naive_conv", "SubTensorOp", "batched_transpose", "Im2d", "Col2Im", "grouped_conv", "gridwise", "miopen")):
+        return "library dense conv (MIOpen, incl. its layout transforms)"
+    if any(k in n for k in ("dwconv", "ln_fwd", "ln_bwd", "sra_", "attn_delta", "diffus", "colsum", "scale_residual")):
+        return "dgtd HIP kernels"
+    if "reduce_kernel" in n:
+        return "torch reductions"
+    if "FusedOptim" in n or "multi_tensor" in n:
+        return "AdamW / multi-tensor"
+    if "fill" in n.lower():
+        return "fills / memsets"
+    if "upsample" in n:
+        return "bilinear resampling"
+    if "avg_pool" in n:
+        return "avg_pool (loss box filter)"
+    if "batch_norm" in n:
+        return "batch_norm"
+    if "copy" in n.lower() or "Cat" in n:
+        return "torch copies / casts / cat"
+    if "elementwise" in n or "prelu" in n:
+        return "torch elementwise"
+    return "other (FFT, pad, roll, ...)"
+
+
 def main():
     path = sys.argv[1]
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
@@ -33,6 +59,13 @@ def main():
         agg[r["Kernel_Name"]][1] += 1
         busy += d
     print(f"# last full step: wall {(t1 - t0) / 1e6:.2f} ms, GPU busy {busy / 1e6:.2f} ms, {b - a} kernel launches")
+    cats = collections.defaultdict(lambda: [0, 0])
+    for k, (d, n) in agg.items():
+        cats[category(k)][0] += d
+        cats[category(k)][1] += n
+    print("# by category:")
+    for k, (d, n) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
+        print(f"#   {d / 1e6:8.2f} ms {n:6d} launches  {k}")
     print(f"# {'ms':>8} {'calls':>6} {'avg_us':>9}  kernel")
     for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         print(f"{d / 1e6:10.3f} {n:6d} {d / n / 1e3:9.1f}  {k[:140]}")
