@@ -1,5 +1,7 @@
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -7,6 +9,7 @@ from torch.autograd.function import once_differentiable
 from .. import _lib as L
 
 _WS = {}
+SPLITK_WGRAD = os.environ.get("DGTD_SPLITK_WGRAD", "1") != "0"   # A/B switch for tools/ and bench runs
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -84,7 +87,7 @@ def _wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     M >= 32768, 1.8x at M = 8192."""
     M = dy2.shape[0]
     S = min(32, M // 1024)
-    if S < 4 or M % S or dy2.dtype == torch.float32:
+    if S < 4 or M % S or dy2.dtype == torch.float32 or not SPLITK_WGRAD:
         return dy2.t() @ x2
     part = torch.bmm(dy2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1))
     return part.sum(0, dtype=torch.float32).to(dy2.dtype)
