@@ -47,230 +47,253 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------ bf16
-// LDS (elements of bf16 unless noted):
-//   Qr[32][72], Gr[32][72]   row-major Q / dO tile (row frags, 16-B reads)
-//   Qt[64][36], Gt[64][36]   transposed tiles (col frags: 4 consecutive queries = 8 B)
-//   Kt[64][SLICE+4]          transposed K slice (col frags for dQ), read once into registers
-//   lse2[32], dlt[32] fp32; dqs[64][33] fp32 (LDS-atomic dQ^T tile; 33-float rows: conflict-free for lane = query)
-struct BwdSmemBf16 {
-  static constexpr int QS = 72, TS = 36, KTS = SLICE + 4;
-  static constexpr size_t off_Qr = 0;
-  static constexpr size_t off_Gr = off_Qr + 32 * QS * 2;
-  static constexpr size_t off_Qt = off_Gr + 32 * QS * 2;
-  static constexpr size_t off_Gt = off_Qt + 64 * TS * 2;
-  static constexpr size_t off_Kt = off_Gt + 64 * TS * 2;
-  static constexpr size_t off_lse = off_Kt + 64 * KTS * 2;
-  static constexpr size_t off_dlt = off_lse + 32 * 4;
-  static constexpr size_t off_dq = off_dlt + 32 * 4;
-  static constexpr size_t total = off_dq + 64 * 33 * 4;
-};
-
-__global__ __launch_bounds__(512) void sra_bwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                    const float* __restrict__ delta, bf16_t* __restrict__ dq,
-                                                    float* __restrict__ dkv, int N, int Nkv, int heads, float scale,
-                                                    int qch) {
-  typedef BwdSmemBf16 L;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::off_Qr);
-  bf16_t* Gr = reinterpret_cast<bf16_t*>(smem + L::off_Gr);
-  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem + L::off_Qt);
-  bf16_t* Gt = reinterpret_cast<bf16_t*>(smem + L::off_Gt);
-  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem + L::off_Kt);
-  float* lse2 = reinterpret_cast<float*>(smem + L::off_lse);
-  float* dlt = reinterpret_cast<float*>(smem + L::off_dlt);
-  float* dqs = reinterpret_cast<float*>(smem + L::off_dq);
-
+// Three launches, no workgroup barrier inside any main loop and no LDS atomics:
+//   prep  : delta = rowsum(dO*O); Qt, dOt = per-head transposes [B,h,64,Np] of q and dO (Np = N rounded up to 64, zero filled)
+//   dK/dV : wave = 32 keys, K/V row fragments live in registers, dK^T/dV^T in accumulators over the query sweep; the query-side
+//           operands are read straight from global memory (row fragments from q/dO, column fragments from Qt/dOt), so the waves
+//           of a workgroup never synchronise.  P and dS (rows = query) go back into the MFMA as A operands (Z = X^T B).
+//   dQ    : the forward kernel's shape: K and V staged once in LDS (row-major), lane = query, S^T/dP^T with rows = key, dS^T
+//           fed back as the B operand and K^T fragments taken with ds_read_b64_tr_b16 (Y = A X).  lse and delta are lane-local.
+__global__ __launch_bounds__(256) void attn_bwd_prep_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ dout,
+                                                          const bf16_t* __restrict__ out, bf16_t* __restrict__ Qt,
+                                                          bf16_t* __restrict__ Gt, float* __restrict__ delta,
+                                                          int N, int Np, int heads) {
+  __shared__ __attribute__((aligned(16))) bf16_t tq[64][72];
+  __shared__ __attribute__((aligned(16))) bf16_t tg[64][72];
   const int C = heads * 64;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const float sl2 = scale * LOG2E;
-  const bf16_t* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
-  const int qt_begin = blockIdx.x * qch;
-  const int qt_end = min(qt_begin + qch, (N + 31) / 32);
-  const int nslices = (Nkv + SLICE - 1) / SLICE;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, row = tid >> 2, seg = tid & 3;   // 64 query rows x 4 segments of 16 channels
+  const int qi = q0 + row;
+  float part = 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int c = seg * 16 + half * 8;
+    bf16x8 qv, gv;
+    if (qi < N) {
+      const size_t off = ((size_t)b * N + qi) * C + hd * 64 + c;
+      qv = *reinterpret_cast<const bf16x8*>(q + off);
+      gv = *reinterpret_cast<const bf16x8*>(dout + off);
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(out + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)gv[j] * (float)ov[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qv[j] = (bf16_t)0.f; gv[j] = (bf16_t)0.f; }
+    }
+    *reinterpret_cast<bf16x8*>(&tq[row][c]) = qv;
+    *reinterpret_cast<bf16x8*>(&tg[row][c]) = gv;
+  }
+  part += __shfl_xor(part, 1, 64);
+  part += __shfl_xor(part, 2, 64);
+  if (seg == 0 && qi < N) delta[((size_t)b * heads + hd) * N + qi] = part;
+  __syncthreads();
+  // transposed write: thread = (channel d, 16-query segment)
+  const int d = tid >> 2;
+  bf16x8 a0, a1, g0, g1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a0[j] = tq[seg * 16 + j][d]; a1[j] = tq[seg * 16 + 8 + j][d];
+    g0[j] = tg[seg * 16 + j][d]; g1[j] = tg[seg * 16 + 8 + j][d];
+  }
+  const size_t o = (((size_t)b * heads + hd) * 64 + d) * Np + q0 + seg * 16;
+  *reinterpret_cast<bf16x8*>(Qt + o) = a0; *reinterpret_cast<bf16x8*>(Qt + o + 8) = a1;
+  *reinterpret_cast<bf16x8*>(Gt + o) = g0; *reinterpret_cast<bf16x8*>(Gt + o + 8) = g1;
+}
 
-  for (int sl = 0; sl < nslices; ++sl) {
-    const int k0 = sl * SLICE;
-    const int kn = min(SLICE, Nkv - k0);           // keys in this slice
-    const int mykey = k0 + wave * 32 + r;          // this lane's key when the key sits on the lane
-    const bool wave_active = wave * 32 < kn;
-    // ---- stage K^T slice, then pull the stationary fragments into registers
-    __syncthreads();
-    for (int i = tid; i < SLICE * 8; i += nthr) {
-      int key = i >> 3, ch = i & 7;
-      bf16x8 kk;
-      if (key < kn) kk = *reinterpret_cast<const bf16x8*>(kvb + (size_t)(k0 + key) * 2 * C + ch * 8);
+__global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                            const bf16_t* __restrict__ dout, const bf16_t* __restrict__ Qt,
+                                                            const bf16_t* __restrict__ Gt, const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, float* __restrict__ dkv,
+                                                            int N, int Np, int Nkv, int heads, float scale, int qch) {
+  const int C = heads * 64;
+  const int bh = blockIdx.z, b = bh / heads, hd = bh % heads;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int kt = blockIdx.y * 4 + wave;
+  if (kt * 32 >= Nkv) return;                       // whole wave leaves; nothing below synchronises across waves
+  const float sl2 = scale * LOG2E;
+  const int key = kt * 32 + r;
+  const bool kok = key < Nkv;
+  bf16x8 kf[4], vf[4];                              // lane (key r, half h): K/V[key][16s+8h .. +7]
+  {
+    const bf16_t* kp = kv + ((size_t)b * Nkv + key) * 2 * C + hd * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
       else
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kk[j] = (bf16_t)0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Kt[(ch * 8 + j) * L::KTS + key] = kk[j];
+        for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
     }
-    __syncthreads();
-    bf16x8 kf[4], vf[4];     // row frags: lane (key r, half h): K/V[key][16s+8h .. +7]
-    bf16x8 kcf[2][2];        // col frags for dQ: [s2][nb], lane (d = nb*32+r, h)
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+  const int qt_end = min((int)(blockIdx.x + 1) * qch, (N + 31) / 32);
+  const size_t tbase = ((size_t)bh * 64 + r) * Np;  // row (d = nb*32 + r) of Qt / Gt
+  const size_t sbase = (size_t)bh * N;
+#pragma unroll 1
+  for (int qt = blockIdx.x * qch; qt < qt_end; ++qt) {
+    const int q0 = qt * 32;
+    const bool qok = (q0 + r) < N;
+    bf16x8 qf[4], gf[4];                            // row fragments: lane (query r, half h)
     {
-      const bool kok = wave_active && (wave * 32 + r) < kn;
-      const bf16_t* kp = kvb + (size_t)mykey * 2 * C + 8 * h;
+      const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
+        if (qok) { qf[s] = *reinterpret_cast<const bf16x8*>(q + off + 16 * s); gf[s] = *reinterpret_cast<const bf16x8*>(dout + off + 16 * s); }
         else
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
+          for (int j = 0; j < 8; ++j) { qf[s][j] = (bf16_t)0.f; gf[s][j] = (bf16_t)0.f; }
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const bf16_t* p = Kt + (nb * 32 + r) * L::KTS + wave * 32 + 16 * s2 + 4 * h;
-          bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 8);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { kcf[s2][nb][j] = lo[j]; kcf[s2][nb][4 + j] = hi[j]; }
-        }
     }
-    f32x16 dk[2], dv[2];
+    const float lse_l = qok ? lse[sbase + q0 + r] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
+    const float dl_l = qok ? delta[sbase + q0 + r] : 0.f;
+    f32x16 sA, pA;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
+      pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qi = mfma_row(i, h);
+      const float l2 = __shfl(lse_l, qi, 64), dl = __shfl(dl_l, qi, 64);
+      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
+      sA[i] = p;                                   // P
+      pA[i] = p * (pA[i] - dl) * scale;            // dS
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf, df;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        // column fragments: lane (d = nb*32 + r, half h), element j <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3)
+        const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
+        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(Gt + o), g1 = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
+        const bf16x4 q0v = *reinterpret_cast<const bf16x4*>(Qt + o), q1v = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
+        bf16x8 gb, qb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gb[j] = g0[j]; gb[4 + j] = g1[j]; qb[j] = q0v[j]; qb[4 + j] = q1v[j]; }
+        dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+        dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = kt * 32 + mfma_row(i, h);
+      if (kk < Nkv) {
+        float* p = dkv + ((size_t)b * Nkv + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
+        atomicAdd(p, dk[nb][i]);
+        atomicAdd(p + C, dv[nb][i]);
+      }
+    }
+}
 
-    for (int qt = qt_begin; qt < qt_end; ++qt) {
-      const int q0 = qt * 32;
-      __syncthreads();  // previous tile fully consumed
-      // ---- stage Q (threads 0..255) and dO (threads 256..511, or the same threads when the block is small)
-      for (int i = tid; i < 512; i += nthr) {
-        const int which = i >> 8, j8 = i & 255, row = j8 >> 3, ch = j8 & 7;
-        const bf16_t* src = (which ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8;
-        bf16x8 v;
-        if (q0 + row < N) v = *reinterpret_cast<const bf16x8*>(src);
+template <int KCH>
+__global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dq,
+                                                          int N, int Nkv, int heads, float scale, int qtw) {
+  constexpr int KS = 72, NT = KCH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vs = Ks + KCH * KS;
+  const int C = heads * 64;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const float sl2 = scale * LOG2E;
+  const bf16_t* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
+  const int nchunks = (Nkv + KCH - 1) / KCH;
+  for (int t = 0; t < qtw; ++t) {
+    const int q0 = ((blockIdx.x * qtw + t) * 4 + wave) * 32;
+    const bool qok = (q0 + r) < N;
+    bf16x8 qf[4], gf[4];                            // B operands: lane (query r, half h)
+    {
+      const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (qok) { qf[s] = *reinterpret_cast<const bf16x8*>(q + off + 16 * s); gf[s] = *reinterpret_cast<const bf16x8*>(dout + off + 16 * s); }
         else
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
-        bf16_t* rowm = which ? Gr : Qr;
-        bf16_t* trn = which ? Gt : Qt;
-        *reinterpret_cast<bf16x8*>(rowm + row * L::QS + ch * 8) = v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) trn[(ch * 8 + j) * L::TS + row] = v[j];
+          for (int j = 0; j < 8; ++j) { qf[s][j] = (bf16_t)0.f; gf[s][j] = (bf16_t)0.f; }
       }
-      for (int i = tid; i < 32; i += nthr) {
-        const bool ok = (q0 + i) < N;
-        const size_t o = ((size_t)b * heads + hd) * N + q0 + i;
-        lse2[i] = ok ? lse[o] * LOG2E : INFINITY;   // +inf -> P = exp2(-inf) = 0 for padded query rows
-        dlt[i] = ok ? delta[o] : 0.f;
-      }
-      for (int i = tid; i < 64 * 33; i += nthr) dqs[i] = 0.f;
-      __syncthreads();
-
-      if (wave_active) {
-        bf16x8 qf[4], gf[4];  // row frags of the Q / dO tile: lane (row r, half h)
+    }
+    const size_t so = ((size_t)b * heads + hd) * N + q0 + r;
+    const float l2 = qok ? lse[so] * LOG2E : INFINITY;
+    const float dl = qok ? delta[so] : 0.f;
+    f32x16 dqa[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          qf[s] = *reinterpret_cast<const bf16x8*>(Qr + r * L::QS + 16 * s + 8 * h);
-          gf[s] = *reinterpret_cast<const bf16x8*>(Gr + r * L::QS + 16 * s + 8 * h);
-        }
-        const bool key_ok_lane = (wave * 32 + r) < kn;
-        // ===== orientation 1: rows = query, lane = key  -> dV, dK
-        {
-          f32x16 sA, pA;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
-            pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int qi = mfma_row(i, h);
-            float p = key_ok_lane ? exp2f(sA[i] * sl2 - lse2[qi]) : 0.f;
-            sA[i] = p;                                   // P
-            pA[i] = p * (pA[i] - dlt[qi]) * scale;       // dS
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pf, df;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-              const bf16_t* gp = Gt + (nb * 32 + r) * L::TS + 16 * s2 + 4 * h;
-              const bf16_t* qp = Qt + (nb * 32 + r) * L::TS + 16 * s2 + 4 * h;
-              bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp), g1 = *reinterpret_cast<const bf16x4*>(gp + 8);
-              bf16x4 q0v = *reinterpret_cast<const bf16x4*>(qp), q1v = *reinterpret_cast<const bf16x4*>(qp + 8);
-              bf16x8 gb, qb;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { gb[j] = g0[j]; gb[4 + j] = g1[j]; qb[j] = q0v[j]; qb[4 + j] = q1v[j]; }
-              dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-              dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
-            }
-          }
-        }
-        // ===== orientation 2: rows = key, lane = query  -> dQ
-        {
-          f32x16 sB, pB;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { sB[i] = 0.f; pB[i] = 0.f; }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sB, 0, 0, 0);   // S^T[key][q]
-            pB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], gf[s], pB, 0, 0, 0);   // dP^T[key][q]
-          }
-          const float l2 = lse2[r], dl = dlt[r];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const bool kok = (wave * 32 + mfma_row(i, h)) < kn;
-            float p = kok ? exp2f(sB[i] * sl2 - l2) : 0.f;
-            pB[i] = p * (pB[i] - dl) * scale;            // dS^T
-          }
-          f32x16 dqa[2];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { dqa[0][i] = 0.f; dqa[1][i] = 0.f; }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 df;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) df[j] = (bf16_t)pB[8 * s2 + j];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-              dqa[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcf[s2][nb], df, dqa[nb], 0, 0, 0);  // dQ^T[d][q]
-          }
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) atomicAdd(&dqs[(nb * 32 + mfma_row(i, h)) * 33 + r], dqa[nb][i]);
-        }
-      }
-      __syncthreads();
-      // ---- dQ tile out (accumulate over key slices through global memory: same workgroup, no race)
-      for (int i = tid; i < 32 * 8; i += nthr) {
-        const int row = i >> 3, ch = i & 7;
-        if (q0 + row < N) {
-          bf16_t* dst = dq + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8;
-          bf16x8 o;
-          if (sl > 0) {
-            bf16x8 prev = *reinterpret_cast<const bf16x8*>(dst);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)prev[j] + dqs[(ch * 8 + j) * 33 + row]);
+    for (int i = 0; i < 16; ++i) { dqa[0][i] = 0.f; dqa[1][i] = 0.f; }
+    for (int c = 0; c < nchunks; ++c) {
+      const int k0 = c * KCH;
+      const int kn = min(KCH, Nkv - k0);
+      if (!(nchunks == 1 && t > 0)) {
+        __syncthreads();
+        for (int i = tid; i < KCH * 8; i += 256) {
+          int key = i >> 3, ch = i & 7;
+          bf16x8 kk, vv;
+          if (key < kn) {
+            const bf16_t* p = kvb + (size_t)(k0 + key) * 2 * C + ch * 8;
+            kk = *reinterpret_cast<const bf16x8*>(p);
+            vv = *reinterpret_cast<const bf16x8*>(p + C);
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)dqs[(ch * 8 + j) * 33 + row];
+            for (int j = 0; j < 8; ++j) { kk[j] = (bf16_t)0.f; vv[j] = (bf16_t)0.f; }
           }
-          *reinterpret_cast<bf16x8*>(dst) = o;
+          *reinterpret_cast<bf16x8*>(Ks + key * KS + ch * 8) = kk;
+          *reinterpret_cast<bf16x8*>(Vs + key * KS + ch * 8) = vv;
+        }
+        __syncthreads();
+      }
+      const int ntiles = (kn + 31) >> 5;
+#pragma unroll 1
+      for (int kt = 0; kt < ntiles; ++kt) {
+        f32x16 sT, pT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sT[i] = 0.f; pT[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * KS + 16 * s + 8 * h);
+          const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * KS + 16 * s + 8 * h);
+          sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], sT, 0, 0, 0);   // S^T[key][q]
+          pT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, gf[s], pT, 0, 0, 0);   // dP^T[key][q]
+        }
+        const bool ragged = (kn & 31) && (kt == ntiles - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = __builtin_amdgcn_exp2f(fmaf(sT[i], sl2, -l2));
+          if (ragged && kt * 32 + mfma_row(i, h) >= kn) p = 0.f;
+          pT[i] = p * (pT[i] - dl) * scale;          // dS^T
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 df;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) df[j] = (bf16_t)pT[8 * s2 + j];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const bf16x8 ka = lds_tr_frag(Ks, KS, kt * 32 + 16 * s2, nb * 32, lane);      // K^T fragment
+            dqa[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, df, dqa[nb], 0, 0, 0);  // dQ^T[d][q]
+          }
         }
       }
     }
-    // ---- flush dK / dV of this wave's keys (fp32 atomics; lanes r = 32 consecutive d)
-    if (wave_active) {
+    if (qok) {
+      bf16_t* op = dq + ((size_t)b * N + q0 + r) * C + hd * 64;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = wave * 32 + mfma_row(i, h);
-          if (key < kn) {
-            float* p = dkv + ((size_t)b * Nkv + k0 + key) * 2 * C + hd * 64 + nb * 32 + r;
-            atomicAdd(p, dk[nb][i]);
-            atomicAdd(p + C, dv[nb][i]);
-          }
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (bf16_t)dqa[nb][4 * g + j];
+          *reinterpret_cast<bf16x4*>(op + nb * 32 + 8 * g + 4 * h) = w;
         }
     }
   }
@@ -461,7 +484,13 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
 
 }  // namespace
 
-extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) { return (int64_t)B * N * heads * sizeof(float); }
+static inline int64_t np_of(int N) { return cdiv(N, 64) * 64; }
+
+// delta [B,h,N] fp32, then (bf16 path) Qt and dOt [B,h,64,Np] bf16
+extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) {
+  const int64_t delta = cdiv((int64_t)B * N * heads * 4, 256) * 256;
+  return delta + 2 * (int64_t)B * heads * 64 * np_of(N) * 2;
+}
 
 extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse,
                                  void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
@@ -471,21 +500,44 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
   hipStream_t st = (hipStream_t)s;
   float* delta = (float*)workspace;
   const int64_t items = (int64_t)B * N * heads;
+  const int qtiles = (int)cdiv(N, 32);
   if (dt == DGTD_BF16) {
-    hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, heads);
+    const int Np = (int)np_of(N);
+    bf16_t* Qt = reinterpret_cast<bf16_t*>((char*)workspace + cdiv(items * 4, 256) * 256);
+    bf16_t* Gt = Qt + (size_t)B * heads * 64 * Np;
+    hipLaunchKernelGGL(attn_bwd_prep_bf16, dim3(Np / 64, heads, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)dout,
+                       (const bf16_t*)out, Qt, Gt, delta, N, Np, heads);
+    DGTD_CHECK_LAUNCH("attn_bwd_prep");
+    // dK/dV: one wave per 32-key tile and query chunk; ~2048 waves in flight, each flushing 16 KB of fp32 atomics at the end
+    const int ktiles = (int)cdiv(Nkv, 32), kgroups = (int)cdiv(ktiles, 4);
+    int qch = 1;
+    while (qch < 64 && (int64_t)cdiv(qtiles, qch * 2) * ktiles * B * heads >= 2048) qch *= 2;
+    DGTD_REQUIRE((int64_t)B * heads <= 65535, "sra_attn_bwd: B*heads too large for the grid");
+    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3((unsigned)cdiv(qtiles, qch), kgroups, B * heads), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)kv, (const bf16_t*)dout, (const bf16_t*)Qt, (const bf16_t*)Gt, lse, (const float*)delta, dkv_f32,
+                       N, Np, Nkv, heads, scale, qch);
+    DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv");
+    // dQ: forward-shaped launch
+    int qtw = 1;
+    while (qtw < 8 && cdiv(N, 128) * B * heads / (qtw * 2) >= 512) qtw *= 2;
+    dim3 grid((unsigned)cdiv(N, 128 * qtw), heads, B);
+    if (Nkv <= 64) {
+      constexpr int KCH = 64;
+      hipLaunchKernelGGL((sra_bwd_dq_bf16<KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const bf16_t*)q, (const bf16_t*)kv,
+                         (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dq, N, Nkv, heads, scale, qtw);
+    } else {
+      constexpr int KCH = 256;
+      hipLaunchKernelGGL((sra_bwd_dq_bf16<KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const bf16_t*)q, (const bf16_t*)kv,
+                         (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dq, N, Nkv, heads, scale, qtw);
+    }
   } else {
     hipLaunchKernelGGL((attn_delta_kernel<float>), dim3((unsigned)cdiv(items * 16, 256)), dim3(256), 0, st, (const float*)out, (const float*)dout, delta, B, N, heads);
-  }
-  DGTD_CHECK_LAUNCH("attn_delta");
-  const int qtiles = (int)cdiv(N, 32);
-  // query tiles per workgroup: enough workgroups to fill 256 CUs, few enough dK/dV flushes
-  int qch = 1;
-  while (qch < 32 && cdiv(qtiles, qch * 2) * B * heads >= 512) qch *= 2;
-  const int nwaves = (int)cdiv(std::min(Nkv, SLICE), 32);
-  dim3 grid((unsigned)cdiv(qtiles, qch), heads, B), block(64 * nwaves);
-  if (dt == DGTD_BF16) {
-    hipLaunchKernelGGL(sra_bwd_bf16, grid, block, BwdSmemBf16::total, st, (const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, lse, delta, (bf16_t*)dq, dkv_f32, N, Nkv, heads, scale, qch);
-  } else {
+    DGTD_CHECK_LAUNCH("attn_delta");
+    // query tiles per workgroup: enough workgroups to fill 256 CUs, few enough dK/dV flushes
+    int qch = 1;
+    while (qch < 32 && cdiv(qtiles, qch * 2) * B * heads >= 512) qch *= 2;
+    const int nwaves = (int)cdiv(std::min(Nkv, SLICE), 32);
+    dim3 grid((unsigned)cdiv(qtiles, qch), heads, B), block(64 * nwaves);
     hipLaunchKernelGGL(sra_bwd_f32, grid, block, BwdSmemF32::total, st, (const float*)q, (const float*)kv, (const float*)dout, lse, delta, (float*)dq, dkv_f32, N, Nkv, heads, scale, qch);
   }
   DGTD_CHECK_LAUNCH("sra_attn_bwd");

@@ -9,7 +9,8 @@
 //   O^T = V^T . P^T : the S^T accumulator (rows = key) is fed straight back as the B operand ("accumulator
 //                     tile as the next MFMA's operand"); A = V^T fragments.  O^T keeps the query on the lane,
 //                     so the online-softmax rescale and the final 1/l are lane-local too.
-// bf16 I/O : v_mfma_f32_32x32x16_bf16, fp32 accumulate, P rounded to bf16 for the second product.
+// bf16 I/O : v_mfma_f32_32x32x16_bf16, fp32 accumulate, P rounded to bf16 for the second product; V^T fragments by
+//            ds_read_b64_tr_b16 from a row-major V tile.
 // fp32 I/O : v_mfma_f32_32x32x2_f32 (exact fp32) — the parity-mode kernel.
 #include "common.h"
 
@@ -19,16 +20,18 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
 // ------------------------------------------------------------------------------------------ bf16
-// LDS image: Ks[KCH][72] (row = key, padded: conflict-free ds_read_b128 of 16-B d-chunks),
-//            Vt[64][KCH+4] (row = d, V transposed at staging time so a lane's 4 consecutive keys are 8 B).
-template <int KCH>
-__global__ __launch_bounds__(256) void sra_fwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+// LDS image: Ks[KCH][72], Vs[KCH][72] — both row-major (row = key), 16-B staging copies only.  The V^T fragments of the second
+// product come from the transposing LDS read (ds_read_b64_tr_b16), so nothing is transposed at staging time.
+// KCH keys are staged per LDS chunk; the score tile is processed KREG keys at a time (online softmax between units) so the
+// kernel stays at <= 256 registers -> 2 waves per SIMD: one wave's softmax VALU overlaps the other's MFMA.
+template <int KCH, int KREG>
+__global__ __launch_bounds__(256, 2) void sra_fwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                     bf16_t* __restrict__ out, float* __restrict__ lse,
                                                     int N, int Nkv, int heads, float scale_log2e, int qtw) {
-  constexpr int KS = 72, VS = KCH + 4, NT = KCH / 32;
+  constexpr int KS = 72, NT = KREG / 32, NU = KCH / KREG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Vt = Ks + KCH * KS;
+  bf16_t* Vs = Ks + KCH * KS;
   const int C = heads * 64;
   const int b = blockIdx.z, hd = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -60,8 +63,7 @@ __global__ __launch_bounds__(256) void sra_fwd_bf16(const bf16_t* __restrict__ q
       const int kn = min(KCH, Nkv - k0);          // valid keys in this chunk
       if (!(nchunks == 1 && t > 0)) {
         __syncthreads();
-        // stage K rows (16-B copies) and V transposed (2-B scatter); zero-fill keys >= kn
-        for (int i = tid; i < KCH * 8; i += 256) {
+        for (int i = tid; i < KCH * 8; i += 256) {   // K and V rows, 16-B copies; zero-fill keys >= kn
           int key = i >> 3, ch = i & 7;
           bf16x8 kk, vv;
           if (key < kn) {
@@ -73,12 +75,16 @@ __global__ __launch_bounds__(256) void sra_fwd_bf16(const bf16_t* __restrict__ q
             for (int j = 0; j < 8; ++j) { kk[j] = (bf16_t)0.f; vv[j] = (bf16_t)0.f; }
           }
           *reinterpret_cast<bf16x8*>(Ks + key * KS + ch * 8) = kk;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + key] = vv[j];
+          *reinterpret_cast<bf16x8*>(Vs + key * KS + ch * 8) = vv;
         }
         __syncthreads();
       }
-      const int ntiles = (kn + 31) >> 5;
+#pragma unroll 1
+      for (int u = 0; u < NU; ++u) {
+      const int ubase = u * KREG;                 // first key of this register unit inside the LDS chunk
+      if (ubase >= kn) break;
+      const int ntiles = (min(kn - ubase, KREG) + 31) >> 5;
+      const bool first_unit = (c == 0 && u == 0);
       // ---- S^T tiles: rows = key, col(lane) = query
       f32x16 sc[NT];
 #pragma unroll
@@ -89,42 +95,44 @@ __global__ __launch_bounds__(256) void sra_fwd_bf16(const bf16_t* __restrict__ q
           for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * KS + 16 * s + 8 * h);
+            bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (ubase + kt * 32 + r) * KS + 16 * s + 8 * h);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+          }
+          if ((kn & 31) && ubase + kt * 32 + 32 > kn) {   // ragged last tile only: padded keys leave the softmax
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              if (ubase + kt * 32 + mfma_row(i, h) >= kn) acc[i] = -INFINITY;
           }
           sc[kt] = acc;
         }
       }
-      // ---- chunk max (log2 domain), mask padded keys
+      // ---- softmax in the log2 domain: one max, one fma + v_exp_f32 + one add per score
       float mc = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        if (kt < ntiles) {
+      for (int kt = 0; kt < NT; ++kt)
+        if (kt < ntiles)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float v = sc[kt][i] * scale_log2e;
-            if (kt * 32 + mfma_row(i, h) >= kn) v = -INFINITY;
-            sc[kt][i] = v;
-            mc = fmaxf(mc, v);
-          }
-        }
-      }
-      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+          for (int i = 0; i < 16; ++i) mc = fmaxf(mc, sc[kt][i]);
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64)) * scale_log2e;     // scale > 0 commutes with max
       const float m_new = fmaxf(m_run, mc);
-      const float alpha = exp2f(m_run - m_new);   // 0 on the first chunk (m_run = -inf)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 0 on the first chunk (m_run = -inf)
       m_run = m_new;
       float ls = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        if (kt < ntiles) {
+      for (int kt = 0; kt < NT; ++kt)
+        if (kt < ntiles)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) { float p = exp2f(sc[kt][i] - m_new); sc[kt][i] = p; ls += p; }
-        }
-      }
+          for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][i], scale_log2e, -m_new));
+            sc[kt][i] = p;
+            ls += p;
+          }
       l_run = l_run * alpha + ls;
+      if (!first_unit) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-      // ---- O^T += V^T . P^T
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      }
+      // ---- O^T += V^T . P^T  (A = V^T fragment by transposing LDS read, B = P^T straight from the accumulator)
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < ntiles) {
@@ -135,17 +143,13 @@ __global__ __launch_bounds__(256) void sra_fwd_bf16(const bf16_t* __restrict__ q
             for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)sc[kt][8 * s2 + j];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-              const bf16_t* vp = Vt + (nb * 32 + r) * VS + kt * 32 + 16 * s2 + 4 * h;
-              bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
-              bf16x4 hi = *reinterpret_cast<const bf16x4*>(vp + 8);
-              bf16x8 a;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+              const bf16x8 a = lds_tr_frag(Vs, KS, ubase + kt * 32 + 16 * s2, nb * 32, lane);
               o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[nb], 0, 0, 0);
             }
           }
         }
       }
+      }  // register unit
     }
     // ---- finalize: lane = query
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -315,12 +319,12 @@ extern "C" int dgtd_sra_attn_fwd(const void* q, const void* kv, void* out, float
   if (dt == DGTD_BF16) {
     if (Nkv <= 64) {
       constexpr int KCH = 64;
-      size_t lds = (size_t)(KCH * 72 + 64 * (KCH + 4)) * 2;
-      hipLaunchKernelGGL((sra_fwd_bf16<KCH>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
+      size_t lds = (size_t)(2 * KCH * 72) * 2;
+      hipLaunchKernelGGL((sra_fwd_bf16<KCH, 64>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
     } else {
       constexpr int KCH = 256;
-      size_t lds = (size_t)(KCH * 72 + 64 * (KCH + 4)) * 2;
-      hipLaunchKernelGGL((sra_fwd_bf16<KCH>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
+      size_t lds = (size_t)(2 * KCH * 72) * 2;
+      hipLaunchKernelGGL((sra_fwd_bf16<KCH, 128>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
     }
   } else if (dt == DGTD_F32) {
     if (Nkv <= 64) {

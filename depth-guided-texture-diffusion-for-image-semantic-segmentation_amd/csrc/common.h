@@ -46,4 +46,24 @@ __device__ __forceinline__ float group_sum(float v, int g) {
 // row index of accumulator register `reg` of a 32x32 MFMA result in lane half `h` (guide §3)
 __device__ __forceinline__ constexpr int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// A-operand fragment of M^T for v_mfma_f32_32x32x16_bf16 taken from a ROW-MAJOR bf16 tile in LDS with the gfx950 transposing
+// read (ds_read_b64_tr_b16, CDNA4 guide T10): lane (r = lane&31, h = lane>>5), fragment element j holds
+//   M[row0 + 8*(j>>2) + 4*h + (j&3)][col0 + r]
+// i.e. exactly the k-permutation of an accumulator tile fed back as the other operand.  Per 16-lane group the instruction reads
+// a 4-row x 16-column block: lane 4q+p supplies the address of row q, columns 4p..4p+3 and receives column (lane&15).
+// Requirements: EXEC all ones, 8-byte aligned addresses (stride*2 and col0*2 multiples of 8).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const bf16_t* base, int stride, int row0, int col0, int lane) {
+  const int i = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
+  const bf16_t* p = base + (row0 + 4 * h + (i >> 2)) * stride + col0 + 16 * g1 + 4 * (i & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * stride));
+  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[j] = l4[j]; f[4 + j] = h4[j]; }
+  return f;
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
