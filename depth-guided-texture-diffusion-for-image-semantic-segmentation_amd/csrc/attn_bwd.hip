@@ -100,6 +100,76 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_bf16(const bf16_t* __restri
   *reinterpret_cast<bf16x8*>(Gt + o) = g0; *reinterpret_cast<bf16x8*>(Gt + o + 8) = g1;
 }
 
+// operands of one 32-query tile for the dK/dV kernel (everything the wave reads from memory per tile)
+struct DkdvTile {
+  bf16x8 qf[4], gf[4];        // row fragments: lane (query r, half h)
+  bf16x4 qc[2][2][2], gc[2][2][2];   // column fragments [s2][nb][lo/hi]: lane (d = nb*32 + r, half h)
+  float lse2, dl;
+};
+
+__device__ __forceinline__ void dkdv_load(DkdvTile& t, const bf16_t* __restrict__ q, const bf16_t* __restrict__ dout,
+                                          const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ Gt,
+                                          const float* __restrict__ lse, const float* __restrict__ delta, int b, int hd, int N,
+                                          int Np, int C, size_t tbase, size_t sbase, int q0, int r, int h) {
+  const bool qok = (q0 + r) < N;
+  const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (qok) { t.qf[s] = *reinterpret_cast<const bf16x8*>(q + off + 16 * s); t.gf[s] = *reinterpret_cast<const bf16x8*>(dout + off + 16 * s); }
+    else
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { t.qf[s][j] = (bf16_t)0.f; t.gf[s][j] = (bf16_t)0.f; }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      // element j of the fragment <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3); Qt/Gt are zero padded to Np, always in range
+      const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
+      t.qc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Qt + o); t.qc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
+      t.gc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Gt + o); t.gc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
+    }
+  t.lse2 = qok ? lse[sbase + q0 + r] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
+  t.dl = qok ? delta[sbase + q0 + r] : 0.f;
+}
+
+__device__ __forceinline__ void dkdv_compute(const DkdvTile& t, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
+                                             f32x16 (&dv)[2], bool kok, float sl2, float scale, int h) {
+  f32x16 sA, pA;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
+    pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int qi = mfma_row(i, h);
+    const float l2 = __shfl(t.lse2, qi, 64), dl = __shfl(t.dl, qi, 64);
+    const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
+    sA[i] = p;                                   // P
+    pA[i] = p * (pA[i] - dl) * scale;            // dS
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    bf16x8 pf, df;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      bf16x8 gb, qb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gb[j] = t.gc[s2][nb][0][j]; gb[4 + j] = t.gc[s2][nb][1][j];
+        qb[j] = t.qc[s2][nb][0][j]; qb[4 + j] = t.qc[s2][nb][1][j];
+      }
+      dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+      dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                             const bf16_t* __restrict__ dout, const bf16_t* __restrict__ Qt,
                                                             const bf16_t* __restrict__ Gt, const float* __restrict__ lse,
@@ -127,60 +197,19 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
-  const int qt_end = min((int)(blockIdx.x + 1) * qch, (N + 31) / 32);
+  const int qt_begin = blockIdx.x * qch;
+  const int qt_end = min(qt_begin + qch, (N + 31) / 32);
   const size_t tbase = ((size_t)bh * 64 + r) * Np;  // row (d = nb*32 + r) of Qt / Gt
   const size_t sbase = (size_t)bh * N;
+  // software pipeline, two named register sets: the next tile's loads are in flight while the current tile is in the MFMAs
+  DkdvTile ta, tb;
+  if (qt_begin < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qt_begin * 32, r, h);
 #pragma unroll 1
-  for (int qt = blockIdx.x * qch; qt < qt_end; ++qt) {
-    const int q0 = qt * 32;
-    const bool qok = (q0 + r) < N;
-    bf16x8 qf[4], gf[4];                            // row fragments: lane (query r, half h)
-    {
-      const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (qok) { qf[s] = *reinterpret_cast<const bf16x8*>(q + off + 16 * s); gf[s] = *reinterpret_cast<const bf16x8*>(dout + off + 16 * s); }
-        else
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { qf[s][j] = (bf16_t)0.f; gf[s][j] = (bf16_t)0.f; }
-      }
-    }
-    const float lse_l = qok ? lse[sbase + q0 + r] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
-    const float dl_l = qok ? delta[sbase + q0 + r] : 0.f;
-    f32x16 sA, pA;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
-      pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int qi = mfma_row(i, h);
-      const float l2 = __shfl(lse_l, qi, 64), dl = __shfl(dl_l, qi, 64);
-      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
-      sA[i] = p;                                   // P
-      pA[i] = p * (pA[i] - dl) * scale;            // dS
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pf, df;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        // column fragments: lane (d = nb*32 + r, half h), element j <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3)
-        const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
-        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(Gt + o), g1 = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
-        const bf16x4 q0v = *reinterpret_cast<const bf16x4*>(Qt + o), q1v = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
-        bf16x8 gb, qb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { gb[j] = g0[j]; gb[4 + j] = g1[j]; qb[j] = q0v[j]; qb[4 + j] = q1v[j]; }
-        dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-        dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
-      }
-    }
+  for (int qt = qt_begin; qt < qt_end; qt += 2) {
+    if (qt + 1 < qt_end) dkdv_load(tb, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 1) * 32, r, h);
+    dkdv_compute(ta, kf, vf, dk, dv, kok, sl2, scale, h);
+    if (qt + 2 < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 2) * 32, r, h);
+    if (qt + 1 < qt_end) dkdv_compute(tb, kf, vf, dk, dv, kok, sl2, scale, h);
   }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)

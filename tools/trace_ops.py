@@ -7,7 +7,7 @@ import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-pats = sys.argv[2:] or ["dwconv", "ln_", "sra_", "attn_delta", "diffus"]
+pats = sys.argv[2:] or ["dwconv", "ln_", "sra_", "attn_delta", "attn_bwd_prep", "diffus", "colsum", "scale_residual"]
 agg = collections.OrderedDict()
 for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
     n = r["Kernel_Name"]
