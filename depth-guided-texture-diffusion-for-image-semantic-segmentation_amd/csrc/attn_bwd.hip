@@ -101,11 +101,26 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_bf16(const bf16_t* __restri
 }
 
 // operands of one 32-query tile for the dK/dV kernel (everything the wave reads from memory per tile)
-struct DkdvTile {
+struct DkdvTile {             // prefetched one tile ahead: what the first two MFMA chains and the softmax need
   bf16x8 qf[4], gf[4];        // row fragments: lane (query r, half h)
-  bf16x4 qc[2][2][2], gc[2][2][2];   // column fragments [s2][nb][lo/hi]: lane (d = nb*32 + r, half h)
   float lse2, dl;
 };
+struct DkdvCols {             // loaded at the top of the tile's own iteration: first used after S, dP and the exponentials
+  bf16x4 qc[2][2][2], gc[2][2][2];   // column fragments [s2][nb][lo/hi]: lane (d = nb*32 + r, half h)
+};
+
+__device__ __forceinline__ void dkdv_load_cols(DkdvCols& t, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ Gt, int Np,
+                                               size_t tbase, int q0, int h) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      // element j of the fragment <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3); Qt/Gt are zero padded to Np, always in range
+      const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
+      t.qc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Qt + o); t.qc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
+      t.gc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Gt + o); t.gc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
+    }
+}
 
 __device__ __forceinline__ void dkdv_load(DkdvTile& t, const bf16_t* __restrict__ q, const bf16_t* __restrict__ dout,
                                           const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ Gt,
@@ -120,20 +135,11 @@ __device__ __forceinline__ void dkdv_load(DkdvTile& t, const bf16_t* __restrict_
 #pragma unroll
       for (int j = 0; j < 8; ++j) { t.qf[s][j] = (bf16_t)0.f; t.gf[s][j] = (bf16_t)0.f; }
   }
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      // element j of the fragment <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3); Qt/Gt are zero padded to Np, always in range
-      const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
-      t.qc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Qt + o); t.qc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
-      t.gc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Gt + o); t.gc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
-    }
   t.lse2 = qok ? lse[sbase + q0 + r] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
   t.dl = qok ? delta[sbase + q0 + r] : 0.f;
 }
 
-__device__ __forceinline__ void dkdv_compute(const DkdvTile& t, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
+__device__ __forceinline__ void dkdv_compute(const DkdvTile& t, const DkdvCols& tc, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
                                              f32x16 (&dv)[2], bool kok, float sl2, float scale, int h) {
   f32x16 sA, pA;
 #pragma unroll
@@ -161,8 +167,8 @@ __device__ __forceinline__ void dkdv_compute(const DkdvTile& t, const bf16x8 (&k
       bf16x8 gb, qb;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        gb[j] = t.gc[s2][nb][0][j]; gb[4 + j] = t.gc[s2][nb][1][j];
-        qb[j] = t.qc[s2][nb][0][j]; qb[4 + j] = t.qc[s2][nb][1][j];
+        gb[j] = tc.gc[s2][nb][0][j]; gb[4 + j] = tc.gc[s2][nb][1][j];
+        qb[j] = tc.qc[s2][nb][0][j]; qb[4 + j] = tc.qc[s2][nb][1][j];
       }
       dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
       dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
@@ -203,13 +209,18 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
   const size_t sbase = (size_t)bh * N;
   // software pipeline, two named register sets: the next tile's loads are in flight while the current tile is in the MFMAs
   DkdvTile ta, tb;
+  DkdvCols tc;
   if (qt_begin < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qt_begin * 32, r, h);
 #pragma unroll 1
   for (int qt = qt_begin; qt < qt_end; qt += 2) {
+    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qt * 32, h);
     if (qt + 1 < qt_end) dkdv_load(tb, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 1) * 32, r, h);
-    dkdv_compute(ta, kf, vf, dk, dv, kok, sl2, scale, h);
-    if (qt + 2 < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 2) * 32, r, h);
-    if (qt + 1 < qt_end) dkdv_compute(tb, kf, vf, dk, dv, kok, sl2, scale, h);
+    dkdv_compute(ta, tc, kf, vf, dk, dv, kok, sl2, scale, h);
+    if (qt + 1 < qt_end) {
+      dkdv_load_cols(tc, Qt, Gt, Np, tbase, (qt + 1) * 32, h);
+      if (qt + 2 < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 2) * 32, r, h);
+      dkdv_compute(tb, tc, kf, vf, dk, dv, kok, sl2, scale, h);
+    }
   }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
