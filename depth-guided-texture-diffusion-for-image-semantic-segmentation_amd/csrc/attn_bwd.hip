@@ -139,43 +139,6 @@ __device__ __forceinline__ void dkdv_load(DkdvTile& t, const bf16_t* __restrict_
   t.dl = qok ? delta[sbase + q0 + r] : 0.f;
 }
 
-__device__ __forceinline__ void dkdv_compute(const DkdvTile& t, const DkdvCols& tc, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
-                                             f32x16 (&dv)[2], bool kok, float sl2, float scale, int h) {
-  f32x16 sA, pA;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
-    pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int qi = mfma_row(i, h);
-    const float l2 = __shfl(t.lse2, qi, 64), dl = __shfl(t.dl, qi, 64);
-    const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
-    sA[i] = p;                                   // P
-    pA[i] = p * (pA[i] - dl) * scale;            // dS
-  }
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    bf16x8 pf, df;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      bf16x8 gb, qb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        gb[j] = tc.gc[s2][nb][0][j]; gb[4 + j] = tc.gc[s2][nb][1][j];
-        qb[j] = tc.qc[s2][nb][0][j]; qb[4 + j] = tc.qc[s2][nb][1][j];
-      }
-      dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-      dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
-    }
-  }
-}
-
 __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                             const bf16_t* __restrict__ dout, const bf16_t* __restrict__ Qt,
                                                             const bf16_t* __restrict__ Gt, const float* __restrict__ lse,
@@ -207,20 +170,54 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
   const int qt_end = min(qt_begin + qch, (N + 31) / 32);
   const size_t tbase = ((size_t)bh * 64 + r) * Np;  // row (d = nb*32 + r) of Qt / Gt
   const size_t sbase = (size_t)bh * N;
-  // software pipeline, two named register sets: the next tile's loads are in flight while the current tile is in the MFMAs
-  DkdvTile ta, tb;
+  // Rotating prefetch with NO extra registers: as soon as the two score chains have consumed the row fragments, the same
+  // registers receive the next tile's rows (in flight during the softmax and the dV/dK products); likewise the column
+  // fragments are re-loaded right after the dV/dK products (in flight during the next tile's score chains and exponentials).
+  DkdvTile t;
   DkdvCols tc;
-  if (qt_begin < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qt_begin * 32, r, h);
+  if (qt_begin < qt_end) {
+    dkdv_load(t, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qt_begin * 32, r, h);
+    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qt_begin * 32, h);
+  }
 #pragma unroll 1
-  for (int qt = qt_begin; qt < qt_end; qt += 2) {
-    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qt * 32, h);
-    if (qt + 1 < qt_end) dkdv_load(tb, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 1) * 32, r, h);
-    dkdv_compute(ta, tc, kf, vf, dk, dv, kok, sl2, scale, h);
-    if (qt + 1 < qt_end) {
-      dkdv_load_cols(tc, Qt, Gt, Np, tbase, (qt + 1) * 32, h);
-      if (qt + 2 < qt_end) dkdv_load(ta, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, (qt + 2) * 32, r, h);
-      dkdv_compute(tb, tc, kf, vf, dk, dv, kok, sl2, scale, h);
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    f32x16 sA, pA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
+      pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
     }
+    const float lse_c = t.lse2, dl_c = t.dl;
+    const int qn = min(qt + 1, qt_end - 1) * 32;   // last iteration re-loads its own tile (harmless, keeps the body branch-free)
+    dkdv_load(t, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qn, r, h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qi = mfma_row(i, h);
+      const float l2 = __shfl(lse_c, qi, 64), dl = __shfl(dl_c, qi, 64);
+      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
+      sA[i] = p;                                   // P
+      pA[i] = p * (pA[i] - dl) * scale;            // dS
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf, df;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        bf16x8 gb, qb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gb[j] = tc.gc[s2][nb][0][j]; gb[4 + j] = tc.gc[s2][nb][1][j];
+          qb[j] = tc.qc[s2][nb][0][j]; qb[4 + j] = tc.qc[s2][nb][1][j];
+        }
+        dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+        dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+      }
+    }
+    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qn, h);
   }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
