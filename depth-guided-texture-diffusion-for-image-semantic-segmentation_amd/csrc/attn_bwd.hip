@@ -47,189 +47,154 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------ bf16
-// Three launches, no workgroup barrier inside any main loop and no LDS atomics:
-//   prep  : delta = rowsum(dO*O); Qt, dOt = per-head transposes [B,h,64,Np] of q and dO (Np = N rounded up to 64, zero filled)
-//   dK/dV : wave = 32 keys, K/V row fragments live in registers, dK^T/dV^T in accumulators over the query sweep; the query-side
-//           operands are read straight from global memory (row fragments from q/dO, column fragments from Qt/dOt), so the waves
-//           of a workgroup never synchronise.  P and dS (rows = query) go back into the MFMA as A operands (Z = X^T B).
+// Two main launches (plus the tiny delta kernel), no LDS atomics, no transposed copies anywhere:
+//   dK/dV : workgroup = up to 8 waves = 256 keys of one (batch, head) and a chunk of query tiles.  Wave w keeps the K/V row
+//           fragments of its 32 keys in registers and dK^T/dV^T in accumulators.  Each 32-query Q/dO tile is staged ONCE per
+//           workgroup into LDS (coalesced 16-B copies, double buffered: one barrier per tile; the next tile's global loads are
+//           in flight during the MFMAs).  Row fragments come from ds_read_b128, column fragments (query on the k axis) from the
+//           transposing read ds_read_b64_tr_b16 of the same row-major tile.  P and dS (rows = query) go back into the MFMA as A
+//           operands (Z = X^T B).
 //   dQ    : the forward kernel's shape: K and V staged once in LDS (row-major), lane = query, S^T/dP^T with rows = key, dS^T
 //           fed back as the B operand and K^T fragments taken with ds_read_b64_tr_b16 (Y = A X).  lse and delta are lane-local.
-__global__ __launch_bounds__(256) void attn_bwd_prep_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ dout,
-                                                          const bf16_t* __restrict__ out, bf16_t* __restrict__ Qt,
-                                                          bf16_t* __restrict__ Gt, float* __restrict__ delta,
-                                                          int N, int Np, int heads) {
-  __shared__ __attribute__((aligned(16))) bf16_t tq[64][72];
-  __shared__ __attribute__((aligned(16))) bf16_t tg[64][72];
-  const int C = heads * 64;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 64;
-  const int tid = threadIdx.x, row = tid >> 2, seg = tid & 3;   // 64 query rows x 4 segments of 16 channels
-  const int qi = q0 + row;
-  float part = 0.f;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int c = seg * 16 + half * 8;
-    bf16x8 qv, gv;
-    if (qi < N) {
-      const size_t off = ((size_t)b * N + qi) * C + hd * 64 + c;
-      qv = *reinterpret_cast<const bf16x8*>(q + off);
-      gv = *reinterpret_cast<const bf16x8*>(dout + off);
-      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(out + off);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part += (float)gv[j] * (float)ov[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { qv[j] = (bf16_t)0.f; gv[j] = (bf16_t)0.f; }
-    }
-    *reinterpret_cast<bf16x8*>(&tq[row][c]) = qv;
-    *reinterpret_cast<bf16x8*>(&tg[row][c]) = gv;
-  }
-  part += __shfl_xor(part, 1, 64);
-  part += __shfl_xor(part, 2, 64);
-  if (seg == 0 && qi < N) delta[((size_t)b * heads + hd) * N + qi] = part;
-  __syncthreads();
-  // transposed write: thread = (channel d, 16-query segment)
-  const int d = tid >> 2;
-  bf16x8 a0, a1, g0, g1;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    a0[j] = tq[seg * 16 + j][d]; a1[j] = tq[seg * 16 + 8 + j][d];
-    g0[j] = tg[seg * 16 + j][d]; g1[j] = tg[seg * 16 + 8 + j][d];
-  }
-  const size_t o = (((size_t)b * heads + hd) * 64 + d) * Np + q0 + seg * 16;
-  *reinterpret_cast<bf16x8*>(Qt + o) = a0; *reinterpret_cast<bf16x8*>(Qt + o + 8) = a1;
-  *reinterpret_cast<bf16x8*>(Gt + o) = g0; *reinterpret_cast<bf16x8*>(Gt + o + 8) = g1;
-}
-
-// operands of one 32-query tile for the dK/dV kernel (everything the wave reads from memory per tile)
-struct DkdvTile {             // prefetched one tile ahead: what the first two MFMA chains and the softmax need
-  bf16x8 qf[4], gf[4];        // row fragments: lane (query r, half h)
-  float lse2, dl;
-};
-struct DkdvCols {             // loaded at the top of the tile's own iteration: first used after S, dP and the exponentials
-  bf16x4 qc[2][2][2], gc[2][2][2];   // column fragments [s2][nb][lo/hi]: lane (d = nb*32 + r, half h)
+struct DkdvSmem {
+  static constexpr int QS = 72;
+  bf16_t q[2][32][QS];
+  bf16_t g[2][32][QS];
+  float lse2[2][32];
+  float dl[2][32];
 };
 
-__device__ __forceinline__ void dkdv_load_cols(DkdvCols& t, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ Gt, int Np,
-                                               size_t tbase, int q0, int h) {
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      // element j of the fragment <-> query q0 + 16*s2 + 8*(j>>2) + 4h + (j&3); Qt/Gt are zero padded to Np, always in range
-      const size_t o = tbase + (size_t)nb * 32 * Np + q0 + 16 * s2 + 4 * h;
-      t.qc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Qt + o); t.qc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Qt + o + 8);
-      t.gc[s2][nb][0] = *reinterpret_cast<const bf16x4*>(Gt + o); t.gc[s2][nb][1] = *reinterpret_cast<const bf16x4*>(Gt + o + 8);
-    }
-}
-
-__device__ __forceinline__ void dkdv_load(DkdvTile& t, const bf16_t* __restrict__ q, const bf16_t* __restrict__ dout,
-                                          const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ Gt,
-                                          const float* __restrict__ lse, const float* __restrict__ delta, int b, int hd, int N,
-                                          int Np, int C, size_t tbase, size_t sbase, int q0, int r, int h) {
-  const bool qok = (q0 + r) < N;
-  const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (qok) { t.qf[s] = *reinterpret_cast<const bf16x8*>(q + off + 16 * s); t.gf[s] = *reinterpret_cast<const bf16x8*>(dout + off + 16 * s); }
-    else
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { t.qf[s][j] = (bf16_t)0.f; t.gf[s][j] = (bf16_t)0.f; }
-  }
-  t.lse2 = qok ? lse[sbase + q0 + r] * LOG2E : INFINITY;   // +inf -> P = 0 for padded query rows
-  t.dl = qok ? delta[sbase + q0 + r] : 0.f;
-}
-
-__global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                            const bf16_t* __restrict__ dout, const bf16_t* __restrict__ Qt,
-                                                            const bf16_t* __restrict__ Gt, const float* __restrict__ lse,
+__global__ __launch_bounds__(512, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dkv,
-                                                            int N, int Np, int Nkv, int heads, float scale, int qch) {
+                                                            int N, int Nkv, int heads, float scale, int qch) {
+  __shared__ __attribute__((aligned(16))) DkdvSmem sm;
+  constexpr int QS = DkdvSmem::QS;
   const int C = heads * 64;
-  const int bh = blockIdx.z, b = bh / heads, hd = bh % heads;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int kt = blockIdx.y * 4 + wave;
-  if (kt * 32 >= Nkv) return;                       // whole wave leaves; nothing below synchronises across waves
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const float sl2 = scale * LOG2E;
-  const int key = kt * 32 + r;
-  const bool kok = key < Nkv;
-  bf16x8 kf[4], vf[4];                              // lane (key r, half h): K/V[key][16s+8h .. +7]
-  {
-    const bf16_t* kp = kv + ((size_t)b * Nkv + key) * 2 * C + hd * 64 + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
-      else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
-    }
-  }
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+  const bf16_t* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
+  const size_t sbase = ((size_t)b * heads + hd) * N;
   const int qt_begin = blockIdx.x * qch;
   const int qt_end = min(qt_begin + qch, (N + 31) / 32);
-  const size_t tbase = ((size_t)bh * 64 + r) * Np;  // row (d = nb*32 + r) of Qt / Gt
-  const size_t sbase = (size_t)bh * N;
-  // Rotating prefetch with NO extra registers: as soon as the two score chains have consumed the row fragments, the same
-  // registers receive the next tile's rows (in flight during the softmax and the dV/dK products); likewise the column
-  // fragments are re-loaded right after the dV/dK products (in flight during the next tile's score chains and exponentials).
-  DkdvTile t;
-  DkdvCols tc;
-  if (qt_begin < qt_end) {
-    dkdv_load(t, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qt_begin * 32, r, h);
-    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qt_begin * 32, h);
-  }
+  const int nslices = (Nkv + SLICE - 1) / SLICE;
+
+  // staging role of this thread: chunk i = tid, tid + nthr, ... of the 512 16-byte chunks {Q tile | dO tile}
+  auto stage_load = [&](int q0, bf16x8 (&v)[4], float& sv) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * nthr;
+      if (i < 512) {
+        const int which = i >> 8, row = (i & 255) >> 3, ch = i & 7;
+        if (q0 + row < N) v[k] = *reinterpret_cast<const bf16x8*>((which ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8);
+        else
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[k][j] = (bf16_t)0.f;
+      }
+    }
+    if (tid < 64) {   // lanes 0-31: lse (log2 domain), lanes 32-63: delta
+      const int row = tid & 31;
+      const bool ok = (q0 + row) < N;
+      sv = tid < 32 ? (ok ? lse[sbase + q0 + row] * LOG2E : INFINITY) : (ok ? delta[sbase + q0 + row] : 0.f);
+    }
+  };
+  auto stage_store = [&](int buf, const bf16x8 (&v)[4], float sv) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * nthr;
+      if (i < 512) {
+        const int which = i >> 8, row = (i & 255) >> 3, ch = i & 7;
+        *reinterpret_cast<bf16x8*>(which ? &sm.g[buf][row][ch * 8] : &sm.q[buf][row][ch * 8]) = v[k];
+      }
+    }
+    if (tid < 32) sm.lse2[buf][tid] = sv;
+    else if (tid < 64) sm.dl[buf][tid - 32] = sv;
+  };
+
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int k0 = sl * SLICE;
+    const int kn = min(SLICE, Nkv - k0);
+    const bool wave_active = wave * 32 < kn;
+    const int key = k0 + wave * 32 + r;
+    const bool kok = wave_active && (wave * 32 + r) < kn;
+    bf16x8 kf[4], vf[4];                            // lane (key r, half h): K/V[key][16s+8h .. +7]
+    {
+      const bf16_t* kp = kvb + (size_t)key * 2 * C + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
+        else
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
+      }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+
+    bf16x8 st[4];
+    float sv = 0.f;
+    __syncthreads();                                 // previous slice fully done with both buffers
+    stage_load(qt_begin * 32, st, sv);
+    stage_store(0, st, sv);
+    __syncthreads();
+    int cur = 0;
 #pragma unroll 1
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
-    f32x16 sA, pA;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+      const bool more = (qt + 1) < qt_end;
+      if (more) stage_load((qt + 1) * 32, st, sv);   // global loads in flight during this tile's MFMAs
+      if (wave_active) {
+        f32x16 sA, pA;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.qf[s], kf[s], sA, 0, 0, 0);   // S[q][key]
-      pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.gf[s], vf[s], pA, 0, 0, 0);   // dP[q][key]
-    }
-    const float lse_c = t.lse2, dl_c = t.dl;
-    const int qn = min(qt + 1, qt_end - 1) * 32;   // last iteration re-loads its own tile (harmless, keeps the body branch-free)
-    dkdv_load(t, q, dout, Qt, Gt, lse, delta, b, hd, N, Np, C, tbase, sbase, qn, r, h);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int qi = mfma_row(i, h);
-      const float l2 = __shfl(lse_c, qi, 64), dl = __shfl(dl_c, qi, 64);
-      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -l2)) : 0.f;
-      sA[i] = p;                                   // P
-      pA[i] = p * (pA[i] - dl) * scale;            // dS
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pf, df;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        bf16x8 gb, qb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gb[j] = tc.gc[s2][nb][0][j]; gb[4 + j] = tc.gc[s2][nb][1][j];
-          qb[j] = tc.qc[s2][nb][0][j]; qb[4 + j] = tc.qc[s2][nb][1][j];
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&sm.q[cur][r][16 * s + 8 * h]);
+          const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&sm.g[cur][r][16 * s + 8 * h]);
+          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sA, 0, 0, 0);   // S[q][key]
+          pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[s], pA, 0, 0, 0);   // dP[q][key]
         }
-        dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-        dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qi = mfma_row(i, h);
+          const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -sm.lse2[cur][qi])) : 0.f;
+          sA[i] = p;                                   // P
+          pA[i] = p * (pA[i] - sm.dl[cur][qi]) * scale;   // dS
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf, df;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            // column fragments: lane (d = nb*32 + r, half h), element j <-> query 16*s2 + 8*(j>>2) + 4h + (j&3)
+            const bf16x8 gb = lds_tr_frag(&sm.g[cur][0][0], QS, 16 * s2, nb * 32, lane);
+            const bf16x8 qb = lds_tr_frag(&sm.q[cur][0][0], QS, 16 * s2, nb * 32, lane);
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+          }
+        }
       }
+      if (more) stage_store(cur ^ 1, st, sv);        // buffer cur^1 was last read before the previous barrier
+      __syncthreads();
+      cur ^= 1;
     }
-    dkdv_load_cols(tc, Qt, Gt, Np, tbase, qn, h);
+    if (wave_active) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kk = wave * 32 + mfma_row(i, h);
+          if (kk < kn) {
+            float* p = dkv + ((size_t)b * Nkv + k0 + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
+            atomicAdd(p, dk[nb][i]);
+            atomicAdd(p + C, dv[nb][i]);
+          }
+        }
+    }
   }
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kk = kt * 32 + mfma_row(i, h);
-      if (kk < Nkv) {
-        float* p = dkv + ((size_t)b * Nkv + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
-        atomicAdd(p, dk[nb][i]);
-        atomicAdd(p + C, dv[nb][i]);
-      }
-    }
 }
 
 template <int KCH>
@@ -521,13 +486,8 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
 
 }  // namespace
 
-static inline int64_t np_of(int N) { return cdiv(N, 64) * 64; }
-
-// delta [B,h,N] fp32, then (bf16 path) Qt and dOt [B,h,64,Np] bf16
-extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) {
-  const int64_t delta = cdiv((int64_t)B * N * heads * 4, 256) * 256;
-  return delta + 2 * (int64_t)B * heads * 64 * np_of(N) * 2;
-}
+// delta [B,h,N] fp32
+extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) { return (int64_t)B * N * heads * sizeof(float); }
 
 extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse,
                                  void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
@@ -539,20 +499,14 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
   const int64_t items = (int64_t)B * N * heads;
   const int qtiles = (int)cdiv(N, 32);
   if (dt == DGTD_BF16) {
-    const int Np = (int)np_of(N);
-    bf16_t* Qt = reinterpret_cast<bf16_t*>((char*)workspace + cdiv(items * 4, 256) * 256);
-    bf16_t* Gt = Qt + (size_t)B * heads * 64 * Np;
-    hipLaunchKernelGGL(attn_bwd_prep_bf16, dim3(Np / 64, heads, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)dout,
-                       (const bf16_t*)out, Qt, Gt, delta, N, Np, heads);
-    DGTD_CHECK_LAUNCH("attn_bwd_prep");
-    // dK/dV: one wave per 32-key tile and query chunk; ~2048 waves in flight, each flushing 16 KB of fp32 atomics at the end
-    const int ktiles = (int)cdiv(Nkv, 32), kgroups = (int)cdiv(ktiles, 4);
+    hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, heads);
+    DGTD_CHECK_LAUNCH("attn_delta");
+    // dK/dV: workgroup = all keys of a 256-key slice (one wave per 32-key tile) x a chunk of query tiles
+    const int nwaves = (int)cdiv(std::min(Nkv, SLICE), 32);
     int qch = 1;
-    while (qch < 64 && (int64_t)cdiv(qtiles, qch * 2) * ktiles * B * heads >= 2048) qch *= 2;
-    DGTD_REQUIRE((int64_t)B * heads <= 65535, "sra_attn_bwd: B*heads too large for the grid");
-    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3((unsigned)cdiv(qtiles, qch), kgroups, B * heads), dim3(256), 0, st, (const bf16_t*)q,
-                       (const bf16_t*)kv, (const bf16_t*)dout, (const bf16_t*)Qt, (const bf16_t*)Gt, lse, (const float*)delta, dkv_f32,
-                       N, Np, Nkv, heads, scale, qch);
+    while (qch < 64 && (int64_t)cdiv(qtiles, qch * 2) * B * heads >= 512) qch *= 2;
+    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3((unsigned)cdiv(qtiles, qch), heads, B), dim3(64 * nwaves), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)kv, (const bf16_t*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, scale, qch);
     DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv");
     // dQ: forward-shaped launch
     int qtw = 1;
