@@ -64,34 +64,37 @@ struct DkdvSmem {
   float dl[2][32];
 };
 
-__global__ __launch_bounds__(512, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+constexpr int KGROUP = 128;   // keys per dK/dV workgroup (4 waves x 32)
+
+__global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dkv,
-                                                            int N, int Nkv, int heads, float scale, int qch) {
+                                                            int N, int Nkv, int heads, int kgroups, float scale, int qch,
+                                                            int use_atomics) {
   __shared__ __attribute__((aligned(16))) DkdvSmem sm;
   constexpr int QS = DkdvSmem::QS;
   const int C = heads * 64;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y / kgroups, kg = blockIdx.y % kgroups;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const float sl2 = scale * LOG2E;
   const bf16_t* kvb = kv + (size_t)b * Nkv * 2 * C + hd * 64;
   const size_t sbase = ((size_t)b * heads + hd) * N;
   const int qt_begin = blockIdx.x * qch;
   const int qt_end = min(qt_begin + qch, (N + 31) / 32);
-  const int nslices = (Nkv + SLICE - 1) / SLICE;
+  const int ktile0 = kg * KGROUP + wave * 32;       // first key of this wave
+  const bool wave_active = ktile0 < Nkv;
+  const int key = ktile0 + r;
+  const bool kok = key < Nkv;
 
-  // staging role of this thread: chunk i = tid, tid + nthr, ... of the 512 16-byte chunks {Q tile | dO tile}
-  auto stage_load = [&](int q0, bf16x8 (&v)[4], float& sv) {
+  // staging role of this thread: chunks tid and tid + 256 of the 512 16-byte chunks {Q tile | dO tile}
+  auto stage_load = [&](int q0, bf16x8 (&v)[2], float& sv) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * nthr;
-      if (i < 512) {
-        const int which = i >> 8, row = (i & 255) >> 3, ch = i & 7;
-        if (q0 + row < N) v[k] = *reinterpret_cast<const bf16x8*>((which ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8);
-        else
+    for (int k = 0; k < 2; ++k) {
+      const int row = tid >> 3, ch = tid & 7;      // k = 0: Q, k = 1: dO
+      if (q0 + row < N) v[k] = *reinterpret_cast<const bf16x8*>((k ? dout : q) + ((size_t)b * N + q0 + row) * C + hd * 64 + ch * 8);
+      else
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[k][j] = (bf16_t)0.f;
-      }
+        for (int j = 0; j < 8; ++j) v[k][j] = (bf16_t)0.f;
     }
     if (tid < 64) {   // lanes 0-31: lse (log2 domain), lanes 32-63: delta
       const int row = tid & 31;
@@ -99,101 +102,88 @@ __global__ __launch_bounds__(512, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
       sv = tid < 32 ? (ok ? lse[sbase + q0 + row] * LOG2E : INFINITY) : (ok ? delta[sbase + q0 + row] : 0.f);
     }
   };
-  auto stage_store = [&](int buf, const bf16x8 (&v)[4], float sv) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * nthr;
-      if (i < 512) {
-        const int which = i >> 8, row = (i & 255) >> 3, ch = i & 7;
-        *reinterpret_cast<bf16x8*>(which ? &sm.g[buf][row][ch * 8] : &sm.q[buf][row][ch * 8]) = v[k];
-      }
-    }
+  auto stage_store = [&](int buf, const bf16x8 (&v)[2], float sv) {
+    const int row = tid >> 3, ch = tid & 7;
+    *reinterpret_cast<bf16x8*>(&sm.q[buf][row][ch * 8]) = v[0];
+    *reinterpret_cast<bf16x8*>(&sm.g[buf][row][ch * 8]) = v[1];
     if (tid < 32) sm.lse2[buf][tid] = sv;
     else if (tid < 64) sm.dl[buf][tid - 32] = sv;
   };
 
-  for (int sl = 0; sl < nslices; ++sl) {
-    const int k0 = sl * SLICE;
-    const int kn = min(SLICE, Nkv - k0);
-    const bool wave_active = wave * 32 < kn;
-    const int key = k0 + wave * 32 + r;
-    const bool kok = wave_active && (wave * 32 + r) < kn;
-    bf16x8 kf[4], vf[4];                            // lane (key r, half h): K/V[key][16s+8h .. +7]
-    {
-      const bf16_t* kp = kvb + (size_t)key * 2 * C + 8 * h;
+  bf16x8 kf[4], vf[4];                              // lane (key r, half h): K/V[key][16s+8h .. +7]
+  {
+    const bf16_t* kp = kvb + (size_t)key * 2 * C + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
+
+  bf16x8 st[2];
+  float sv = 0.f;
+  stage_load(qt_begin * 32, st, sv);
+  stage_store(0, st, sv);
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const bool more = (qt + 1) < qt_end;
+    if (more) stage_load((qt + 1) * 32, st, sv);     // global loads in flight during this tile's MFMAs
+    if (wave_active) {
+      f32x16 sA, pA;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (kok) { kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8*>(kp + C + 16 * s); }
-        else
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&sm.q[cur][r][16 * s + 8 * h]);
+        const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&sm.g[cur][r][16 * s + 8 * h]);
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sA, 0, 0, 0);   // S[q][key]
+        pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[s], pA, 0, 0, 0);   // dP[q][key]
+      }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16_t)0.f; vf[s][j] = (bf16_t)0.f; }
+      for (int i = 0; i < 16; ++i) {
+        const int qi = mfma_row(i, h);
+        const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -sm.lse2[cur][qi])) : 0.f;
+        sA[i] = p;                                   // P
+        pA[i] = p * (pA[i] - sm.dl[cur][qi]) * scale;   // dS
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf, df;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          // column fragments: lane (d = nb*32 + r, half h), element j <-> query 16*s2 + 8*(j>>2) + 4h + (j&3)
+          const bf16x8 gb = lds_tr_frag(&sm.g[cur][0][0], QS, 16 * s2, nb * 32, lane);
+          const bf16x8 qb = lds_tr_frag(&sm.q[cur][0][0], QS, 16 * s2, nb * 32, lane);
+          dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
+          dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+        }
       }
     }
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f; }
-
-    bf16x8 st[4];
-    float sv = 0.f;
-    __syncthreads();                                 // previous slice fully done with both buffers
-    stage_load(qt_begin * 32, st, sv);
-    stage_store(0, st, sv);
+    if (more) stage_store(cur ^ 1, st, sv);          // buffer cur^1 was last read before the previous barrier
     __syncthreads();
-    int cur = 0;
-#pragma unroll 1
-    for (int qt = qt_begin; qt < qt_end; ++qt) {
-      const bool more = (qt + 1) < qt_end;
-      if (more) stage_load((qt + 1) * 32, st, sv);   // global loads in flight during this tile's MFMAs
-      if (wave_active) {
-        f32x16 sA, pA;
+    cur ^= 1;
+  }
+  if (wave_active) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sA[i] = 0.f; pA[i] = 0.f; }
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&sm.q[cur][r][16 * s + 8 * h]);
-          const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&sm.g[cur][r][16 * s + 8 * h]);
-          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sA, 0, 0, 0);   // S[q][key]
-          pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[s], pA, 0, 0, 0);   // dP[q][key]
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int qi = mfma_row(i, h);
-          const float p = kok ? __builtin_amdgcn_exp2f(fmaf(sA[i], sl2, -sm.lse2[cur][qi])) : 0.f;
-          sA[i] = p;                                   // P
-          pA[i] = p * (pA[i] - sm.dl[cur][qi]) * scale;   // dS
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 pf, df;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sA[8 * s2 + j]; df[j] = (bf16_t)pA[8 * s2 + j]; }
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            // column fragments: lane (d = nb*32 + r, half h), element j <-> query 16*s2 + 8*(j>>2) + 4h + (j&3)
-            const bf16x8 gb = lds_tr_frag(&sm.g[cur][0][0], QS, 16 * s2, nb * 32, lane);
-            const bf16x8 qb = lds_tr_frag(&sm.q[cur][0][0], QS, 16 * s2, nb * 32, lane);
-            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
-          }
+      for (int i = 0; i < 16; ++i) {
+        const int kk = ktile0 + mfma_row(i, h);
+        if (kk < Nkv) {
+          float* p = dkv + ((size_t)b * Nkv + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
+          if (use_atomics) { atomicAdd(p, dk[nb][i]); atomicAdd(p + C, dv[nb][i]); }
+          else { p[0] = dk[nb][i]; p[C] = dv[nb][i]; }   // this workgroup swept every query: the sum is complete
         }
       }
-      if (more) stage_store(cur ^ 1, st, sv);        // buffer cur^1 was last read before the previous barrier
-      __syncthreads();
-      cur ^= 1;
-    }
-    if (wave_active) {
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int kk = wave * 32 + mfma_row(i, h);
-          if (kk < kn) {
-            float* p = dkv + ((size_t)b * Nkv + k0 + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
-            atomicAdd(p, dk[nb][i]);
-            atomicAdd(p + C, dv[nb][i]);
-          }
-        }
-    }
   }
 }
 
@@ -501,12 +491,16 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
   if (dt == DGTD_BF16) {
     hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, heads);
     DGTD_CHECK_LAUNCH("attn_delta");
-    // dK/dV: workgroup = all keys of a 256-key slice (one wave per 32-key tile) x a chunk of query tiles
-    const int nwaves = (int)cdiv(std::min(Nkv, SLICE), 32);
-    int qch = 1;
-    while (qch < 64 && (int64_t)cdiv(qtiles, qch * 2) * B * heads >= 512) qch *= 2;
-    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3((unsigned)cdiv(qtiles, qch), heads, B), dim3(64 * nwaves), 0, st, (const bf16_t*)q,
-                       (const bf16_t*)kv, (const bf16_t*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, scale, qch);
+    // dK/dV: workgroup = 128 keys (4 waves) x a chunk of query tiles.  Keys are split across workgroups; queries are split
+    // only as far as needed to put ~1 workgroup on every CU, because every extra query chunk costs one more fp32-atomic flush
+    // of the whole dK/dV (the chip-wide atomic rate is ~1.3 TB/s).  With a single chunk the result is stored plainly.
+    const int kgroups = (int)cdiv(Nkv, KGROUP);
+    DGTD_REQUIRE((int64_t)heads * kgroups <= 65535, "sra_attn_bwd: heads*kgroups too large for the grid");
+    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(256, (int64_t)B * heads * kgroups)));
+    const int qch = (int)cdiv(qtiles, nq);
+    const int nqc = (int)cdiv(qtiles, qch);
+    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv,
+                       (const bf16_t*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, kgroups, scale, qch, nqc > 1 ? 1 : 0);
     DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv");
     // dQ: forward-shaped launch
     int qtw = 1;
