@@ -356,10 +356,10 @@ class prompt_encoder(nn.Module):
     def fft(self, x, rate):
         return fft_highpass(x, rate)
 
-    def forward(self, image, cues, cross=False):
+    def forward(self, image, cues, cross=False, x_hp=None):
         with torch.autocast("cuda", enabled=False):
             image32 = image.float()
-            x = self.fft(image32, self.freq_nums)
+            x = self.fft(image32, self.freq_nums) if x_hp is None else x_hp
             # one fused launch per (image, latent channel): regressor + depth embedding + 4 propagation steps
             reg = self.propagation_weight_regressor.reg
             x4 = ops.diffuser_state(x, cues, *wb(reg), *wb(self.encoder1))
@@ -447,11 +447,11 @@ class PyramidVisionTransformerImpr(nn.Module):
         self.apply(_init_weights)
         self.batch = 0
 
-    def forward_features(self, x, depth):
+    def forward_features(self, x, depth, x_hp=None):
         self.batch += 1
         B = x.shape[0]
         image = x
-        embedding1, embedding3 = self.prompt_encoder(image, depth)
+        embedding1, embedding3 = self.prompt_encoder(image, depth, x_hp=x_hp)
         embedding3 = embedding3.contiguous(memory_format=torch.channels_last)
         outs = []
         for i in range(4):
@@ -464,8 +464,8 @@ class PyramidVisionTransformerImpr(nn.Module):
             outs.append(x)
         return embedding1, outs
 
-    def forward(self, x, depth):
-        return self.forward_features(x, depth)
+    def forward(self, x, depth, x_hp=None):
+        return self.forward_features(x, depth, x_hp)
 
 
 class pvt_v2_b2(PyramidVisionTransformerImpr):
@@ -584,8 +584,8 @@ class Hitnet(nn.Module):
         self.compress_out = BasicConv2d(2 * channel, channel, kernel_size=8, stride=4, padding=2)
         self.compress_out2 = BasicConv2d(2 * channel, channel, kernel_size=1)
 
-    def forward(self, x, pred_normal):
-        embedding1, (x1, x2, x3, x4) = self.backbone(x, pred_normal)
+    def forward(self, x, pred_normal, x_hp=None):
+        embedding1, (x1, x2, x3, x4) = self.backbone(x, pred_normal, x_hp)
         cim = self.decoder_level1(x1)
         x2_t, x3_t, x4_t = self.Translayer2_1(x2), self.Translayer3_1(x3), self.Translayer4_1(x4)
         stage_loss, cfm = [], None
@@ -668,18 +668,22 @@ class cod(nn.Module):
         else:
             self._dp_plan["masks"] = None
 
-    def _run(self, input, depth):
+    def _run(self, input, depth, x_hp=None):
         self._draw_drop_path(input.shape[0])
         if self.compute_dtype == torch.bfloat16:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                return self.hitnet(input, depth)
-        return self.hitnet(input, depth)
+            with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=not torch.cuda.is_current_stream_capturing()):
+                return self.hitnet(input, depth, x_hp)
+        return self.hitnet(input, depth, x_hp)
 
-    def forward(self, raw, input, label, depth, mode="loss"):
+    def high_pass(self, input):
+        """The FFT high-pass image (cod.py:1288) on its own: lets a hipGraph-captured step keep rocFFT outside the graph."""
+        return fft_highpass(_stack(input).float(), self.hitnet.backbone.prompt_encoder.freq_nums)
+
+    def forward(self, raw, input, label, depth, mode="loss", x_hp=None):
         input, label, depth = _stack(input), _stack(label), _stack(depth)
         if not input.is_cuda:
             raise RuntimeError("dgtd.nn.cod runs on the MI355X HIP device only; the CPU restatement is oracle/cod_cpu.py")
-        embedding1, P1, P2 = self._run(input, depth)
+        embedding1, P1, P2 = self._run(input, depth, x_hp)
         if mode == "loss":
             label = label.float()
             weit = loss_weight(label)
