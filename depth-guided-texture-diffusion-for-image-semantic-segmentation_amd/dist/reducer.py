@@ -149,20 +149,10 @@ class GradReducer:
             if b["wflat"] is not None:
                 b["wflat"].copy_(b["mflat"])
 
-    def freeze_for_graph(self) -> None:
-        """Call right after capturing forward+backward into a hipGraph: the leaf gradient tensors produced during capture
-        live in the graph's memory pool and are rewritten by every replay, so keep them and stop resetting ``.grad``."""
-        for b in self.buckets:
-            b["static_grads"] = [leaf.grad for leaf in b["leaves"]]
-        self.overlap = False
-
     def zero_grad(self) -> None:
         """Replaces optimizer.zero_grad(): leaves get .grad = None so autograd hands gradients over without an
         accumulate kernel; nothing is memset (the flat buckets are fully overwritten by _gather)."""
         for b in self.buckets:
-            if "static_grads" in b:
-                b["done"] = False
-                continue
             b["pending"], b["done"] = b["n"], False
             for leaf in b["leaves"]:
                 leaf.grad = None
@@ -181,12 +171,11 @@ class GradReducer:
         low-precision segment) instead of a copy kernel per parameter; then restore the master .grad views."""
         flat, k, nw = bucket["flat"], bucket["k_work"], bucket["n_work"]
         leaves, gviews = bucket["leaves"], bucket["gviews"]
-        static = bucket.get("static_grads")
 
         def seg(lo, hi, out):
             if lo == hi:
                 return
-            gs = static[lo:hi] if static is not None else [l.grad for l in leaves[lo:hi]]
+            gs = [l.grad for l in leaves[lo:hi]]
             if any(g is None for g in gs):   # a parameter unused this step: fall back to per-tensor copies
                 for g, gv in zip(gs, gviews[lo:hi]):
                     gv.zero_() if g is None else gv.copy_(g)
@@ -198,14 +187,9 @@ class GradReducer:
 
         seg(0, k, flat[:nw])
         seg(k, len(leaves), flat[nw:])
-        if static is None:
-            for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
-                leaf.grad = None        # free the per-leaf gradient
-                p.grad = gv
-        else:
-            for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
-                if leaf is not p:       # masters of working copies read the flat bucket; plain leaves keep their graph tensor
-                    p.grad = gv
+        for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
+            leaf.grad = None            # free the per-leaf gradient
+            p.grad = gv
         bucket["done"] = True
 
     def _launch(self, bucket) -> None:

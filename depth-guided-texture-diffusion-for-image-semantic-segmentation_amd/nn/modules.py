@@ -671,12 +671,13 @@ class cod(nn.Module):
     def _run(self, input, depth, x_hp=None):
         self._draw_drop_path(input.shape[0])
         if self.compute_dtype == torch.bfloat16:
-            with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=not torch.cuda.is_current_stream_capturing()):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
                 return self.hitnet(input, depth, x_hp)
         return self.hitnet(input, depth, x_hp)
 
     def high_pass(self, input):
-        """The FFT high-pass image (cod.py:1288) on its own: lets a hipGraph-captured step keep rocFFT outside the graph."""
+        """The FFT high-pass image (cod.py:1288) on its own (it depends on the input only, so a data pipeline can
+        precompute it and pass it as ``x_hp``)."""
         return fft_highpass(_stack(input).float(), self.hitnet.backbone.prompt_encoder.freq_nums)
 
     def forward(self, raw, input, label, depth, mode="loss", x_hp=None):
