@@ -34,6 +34,9 @@ SIGNATURES = {
     "dgtd_colsum_workspace": (_i64, [_i]),
     "dgtd_scale_residual_bwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _vp, _i64, _i, _i64, _i, _vp]),
     "dgtd_colsum": (_i, [_vp, _fp, _vp, _i64, _i, _i, _vp]),
+    "dgtd_seg_loss_workspace": (_i64, [_i, _i]),
+    "dgtd_seg_loss_fwd": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
+    "dgtd_seg_loss_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "dgtd_diffuser_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuser_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),

@@ -1,0 +1,194 @@
+// loss.hip — fused structure loss of the five deep-supervision heads (fp32).
+// Replaces, for training: the x8 bilinear up-sampling of the 1-channel head maps (twig/model/cod.py:796, :806; align_corners=False)
+// and cod.cal_loss (cod.py:76-85) called five times (cod.py:137-142): weit = 1 + 5|avgpool31(gt) - gt|, weighted BCE-with-logits +
+// weighted soft IoU per sample, mean over the batch, mixed with weights (0, .2, .4, .6) for P1[0..3] and 1 for P2.
+//
+// The edge weight depends on the label only -> computed ONCE (the reference evaluates the 31x31 box filter five times), the five
+// full-resolution logit maps are never materialised: every label pixel bilinearly samples the five low-resolution maps on the fly.
+// HBM-bound: algorithmic bytes = label read (4 B/px) + weight write/read (8 B/px) + the low-res maps (L2 resident).
+//   box   : separable 31-tap running sums through LDS (32x32 output tile, 62x62 input tile)
+//   fwd   : per (map k, sample b): A = sum w*bce, I = sum w*sig*gt, U = sum w*(sig+gt); per b: W = sum w   (wave shuffles + atomics)
+//   bwd   : gather per low-res pixel over the <= 16x16 label pixels it touches (transpose of the bilinear sampling)
+#include "common.h"
+
+namespace {
+
+constexpr int NMAP = 5, RAD = 15, TILE = 32, HALO = TILE + 2 * RAD;
+
+__device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, int& i1, float& l1) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// weit[b][y][x] = 1 + 5*|boxmean31(gt) - gt|  (zero padding, divisor 961: F.avg_pool2d count_include_pad=True); wsum[b] += sum weit
+__global__ __launch_bounds__(256) void loss_weight_kernel(const float* __restrict__ gt, float* __restrict__ weit,
+                                                          float* __restrict__ wsum, int S) {
+  __shared__ float in[HALO][HALO + 1];
+  __shared__ float hs[HALO][TILE + 1];
+  __shared__ float red[4];
+  const int b = blockIdx.z, ty0 = blockIdx.y * TILE, tx0 = blockIdx.x * TILE, tid = threadIdx.x;
+  const float* g = gt + (size_t)b * S * S;
+  for (int i = tid; i < HALO * HALO; i += 256) {
+    const int yy = i / HALO, xx = i % HALO, y = ty0 + yy - RAD, x = tx0 + xx - RAD;
+    in[yy][xx] = (y >= 0 && y < S && x >= 0 && x < S) ? g[(size_t)y * S + x] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < HALO * TILE; i += 256) {     // horizontal 31-tap sums
+    const int yy = i / TILE, xx = i % TILE;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * RAD + 1; ++k) s += in[yy][xx + k];
+    hs[yy][xx] = s;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int i = tid; i < TILE * TILE; i += 256) {     // vertical 31-tap sums
+    const int yy = i / TILE, xx = i % TILE, y = ty0 + yy, x = tx0 + xx;
+    if (y < S && x < S) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2 * RAD + 1; ++k) s += hs[yy + k][xx];
+      const float w = 1.f + 5.f * fabsf(s * (1.f / 961.f) - in[yy + RAD][xx + RAD]);
+      weit[(size_t)b * S * S + (size_t)y * S + x] = w;
+      acc += w;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&wsum[b], red[0] + red[1] + red[2] + red[3]);
+}
+
+// sums[k][b][3] += {A, I, U} over this block's pixels.  lo: [NMAP][B][hs][hs] low-res logits.
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ lo, const float* __restrict__ gt,
+                                                       const float* __restrict__ weit, float* __restrict__ sums, int B, int S, int hs) {
+  __shared__ float red[4][NMAP * 3];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float scale = (float)hs / (float)S;
+  float acc[NMAP][3];
+#pragma unroll
+  for (int k = 0; k < NMAP; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+  const size_t plane = (size_t)b * S * S;
+  for (int i = blockIdx.x * 256 + tid; i < S * S; i += gridDim.x * 256) {
+    const int y = i / S, x = i % S;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(y, scale, hs, y0, y1, ly);
+    bil_src(x, scale, hs, x0, x1, lx);
+    const float w = weit[plane + i], t = gt[plane + i];
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+    for (int k = 0; k < NMAP; ++k) {
+      const float* m = lo + ((size_t)k * B + b) * hs * hs;
+      const float z = w00 * m[y0 * hs + x0] + w01 * m[y0 * hs + x1] + w10 * m[y1 * hs + x0] + w11 * m[y1 * hs + x1];
+      const float e = expf(-fabsf(z));
+      const float bce = fmaxf(z, 0.f) - z * t + log1pf(e);
+      const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      acc[k][0] += w * bce;
+      acc[k][1] += w * sg * t;
+      acc[k][2] += w * (sg + t);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NMAP; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float v = wave_sum(acc[k][j]);
+      if ((tid & 63) == 0) red[tid >> 6][k * 3 + j] = v;
+    }
+  __syncthreads();
+  if (tid < NMAP * 3) atomicAdd(&sums[((size_t)(tid / 3) * B + b) * 3 + tid % 3], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+// loss = sum_k mix[k] * mean_b( A/W + 1 - (I+1)/(U-I+1) )   ; one thread
+__global__ void loss_finish_kernel(const float* __restrict__ sums, const float* __restrict__ wsum, const float* __restrict__ mix,
+                                   float* __restrict__ loss, int B) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float tot = 0.f;
+  for (int k = 0; k < NMAP; ++k) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* p = sums + ((size_t)k * B + b) * 3;
+      s += p[0] / wsum[b] + 1.f - (p[1] + 1.f) / (p[2] - p[1] + 1.f);
+    }
+    tot += mix[k] * s / (float)B;
+  }
+  loss[0] = tot;
+}
+
+// dlo[k][b][cy][cx] = gscale * mix[k]/B * sum_pixels bilinear_weight(pixel -> cell) * dL/dz(pixel)
+__global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ lo, const float* __restrict__ gt,
+                                                      const float* __restrict__ weit, const float* __restrict__ sums,
+                                                      const float* __restrict__ wsum, const float* __restrict__ mix,
+                                                      const float* __restrict__ gout, float* __restrict__ dlo, int B, int S, int hs) {
+  const int cell = blockIdx.x, cy = cell / hs, cx = cell % hs, b = blockIdx.y, k = blockIdx.z, lane = threadIdx.x;
+  const float scale = (float)hs / (float)S;
+  const float* m = lo + ((size_t)k * B + b) * hs * hs;
+  const float* p3 = sums + ((size_t)k * B + b) * 3;
+  const float I = p3[1], U = p3[2], Nn = I + 1.f, Dn = U - I + 1.f, Wb = wsum[b];
+  const float coef = gout[0] * mix[k] / (float)B;
+  // label pixels that can touch this cell: src in (c-1, c+1)
+  const int lo_y = max(0, (int)floorf((cy - 0.5f) / scale - 0.5f) - 1), hi_y = min(S - 1, (int)ceilf((cy + 1.5f) / scale - 0.5f) + 1);
+  const int lo_x = max(0, (int)floorf((cx - 0.5f) / scale - 0.5f) - 1), hi_x = min(S - 1, (int)ceilf((cx + 1.5f) / scale - 0.5f) + 1);
+  const int ny = hi_y - lo_y + 1, nx = hi_x - lo_x + 1;
+  const size_t plane = (size_t)b * S * S;
+  float acc = 0.f;
+  for (int i = lane; i < ny * nx; i += 64) {
+    const int y = lo_y + i / nx, x = lo_x + i % nx;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(y, scale, hs, y0, y1, ly);
+    bil_src(x, scale, hs, x0, x1, lx);
+    const float wy = (y0 == cy ? 1.f - ly : 0.f) + (y1 == cy ? ly : 0.f);
+    const float wx = (x0 == cx ? 1.f - lx : 0.f) + (x1 == cx ? lx : 0.f);
+    const float wc = wy * wx;
+    if (wc != 0.f) {
+      const float z = (1.f - ly) * ((1.f - lx) * m[y0 * hs + x0] + lx * m[y0 * hs + x1]) + ly * ((1.f - lx) * m[y1 * hs + x0] + lx * m[y1 * hs + x1]);
+      const float w = weit[plane + (size_t)y * S + x], t = gt[plane + (size_t)y * S + x];
+      const float e = expf(-fabsf(z));
+      const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      const float ds = sg * (1.f - sg);
+      const float g = w * (sg - t) / Wb - w * ds * (t * Dn - Nn * (1.f - t)) / (Dn * Dn);
+      acc += wc * g;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dlo[((size_t)k * B + b) * hs * hs + cell] = coef * acc;
+}
+
+}  // namespace
+
+extern "C" int64_t dgtd_seg_loss_workspace(int B, int S) { return ((int64_t)B * S * S + (int64_t)5 * B * 3 + B) * sizeof(float); }
+
+// workspace layout: weit [B,S,S] | sums [5,B,3] | wsum [B]   (kept by the caller between fwd and bwd)
+extern "C" int dgtd_seg_loss_fwd(const float* lo, const float* label, const float* mix, float* loss, void* workspace, int B, int S,
+                                 int hs, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && S > 0 && hs > 0, "seg_loss_fwd: bad sizes B=%d S=%d hs=%d", B, S, hs);
+  hipStream_t st = (hipStream_t)s;
+  float* weit = (float*)workspace;
+  float* sums = weit + (size_t)B * S * S;
+  float* wsum = sums + (size_t)NMAP * B * 3;
+  hipError_t e = hipMemsetAsync(sums, 0, ((size_t)NMAP * B * 3 + B) * sizeof(float), st);
+  if (e != hipSuccess) DGTD_FAIL(3, "seg_loss_fwd: memset failed: %s", hipGetErrorString(e));
+  const int tiles = (int)cdiv(S, TILE);
+  hipLaunchKernelGGL(loss_weight_kernel, dim3(tiles, tiles, B), dim3(256), 0, st, label, weit, wsum, S);
+  DGTD_CHECK_LAUNCH("loss_weight");
+  const int gx = (int)std::min<int64_t>(cdiv((int64_t)S * S, 256 * 4), 256);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(gx, B), dim3(256), 0, st, lo, label, (const float*)weit, sums, B, S, hs);
+  DGTD_CHECK_LAUNCH("loss_fwd");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, (const float*)wsum, mix, loss, B);
+  DGTD_CHECK_LAUNCH("loss_finish");
+  return 0;
+}
+
+extern "C" int dgtd_seg_loss_bwd(const float* lo, const float* label, const float* mix, const float* gout, float* dlo,
+                                 const void* workspace, int B, int S, int hs, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && S > 0 && hs > 0, "seg_loss_bwd: bad sizes B=%d S=%d hs=%d", B, S, hs);
+  const float* weit = (const float*)workspace;
+  const float* sums = weit + (size_t)B * S * S;
+  const float* wsum = sums + (size_t)NMAP * B * 3;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(hs * hs, B, NMAP), dim3(64), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
+  DGTD_CHECK_LAUNCH("loss_bwd");
+  return 0;
+}

@@ -584,7 +584,9 @@ class Hitnet(nn.Module):
         self.compress_out = BasicConv2d(2 * channel, channel, kernel_size=8, stride=4, padding=2)
         self.compress_out2 = BasicConv2d(2 * channel, channel, kernel_size=1)
 
-    def forward(self, x, pred_normal, x_hp=None):
+    def forward(self, x, pred_normal, x_hp=None, lowres: bool = False):
+        """``lowres=True`` returns the five head maps BEFORE their x8 up-sampling (the fused training loss samples them on
+        the fly, ops.seg_loss); the default returns the reference's full-resolution maps (cod.py:796, :806)."""
         embedding1, (x1, x2, x3, x4) = self.backbone(x, pred_normal, x_hp)
         cim = self.decoder_level1(x1)
         x2_t, x3_t, x4_t = self.Translayer2_1(x2), self.Translayer3_1(x3), self.Translayer4_1(x4)
@@ -598,10 +600,11 @@ class Hitnet(nn.Module):
                 x2_t = self.compress_out2(torch.cat((x2_t, cfm), 1))
             x2f = self.decoder_level2(torch.cat((x2_t, _up(x3f, 2, True)), 1))
             cfm = self.conv4(x2f)
-            stage_loss.append(_up(self.out_CFM(cfm).float(), 8, False))
+            pred = self.out_CFM(cfm).float()
+            stage_loss.append(pred if lowres else _up(pred, 8, False))
         T2 = _up(self.Translayer2_0(cim), 0.5, True)
-        pred2 = _up(self.out_SAM(self.SAM(cfm, T2)).float(), 8, False)
-        return embedding1, stage_loss, pred2
+        pred2 = self.out_SAM(self.SAM(cfm, T2)).float()
+        return embedding1, stage_loss, (pred2 if lowres else _up(pred2, 8, False))
 
 
 # ------------------------------------------------------------------------------------------------ losses / top level
@@ -668,12 +671,12 @@ class cod(nn.Module):
         else:
             self._dp_plan["masks"] = None
 
-    def _run(self, input, depth, x_hp=None):
+    def _run(self, input, depth, x_hp=None, lowres=False):
         self._draw_drop_path(input.shape[0])
         if self.compute_dtype == torch.bfloat16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                return self.hitnet(input, depth, x_hp)
-        return self.hitnet(input, depth, x_hp)
+                return self.hitnet(input, depth, x_hp, lowres)
+        return self.hitnet(input, depth, x_hp, lowres)
 
     def high_pass(self, input):
         """The FFT high-pass image (cod.py:1288) on its own (it depends on the input only, so a data pipeline can
@@ -684,18 +687,15 @@ class cod(nn.Module):
         input, label, depth = _stack(input), _stack(label), _stack(depth)
         if not input.is_cuda:
             raise RuntimeError("dgtd.nn.cod runs on the MI355X HIP device only; the CPU restatement is oracle/cod_cpu.py")
-        embedding1, P1, P2 = self._run(input, depth, x_hp)
         if mode == "loss":
-            label = label.float()
-            weit = loss_weight(label)
-            losses = [cal_loss(p, label, weit) for p in P1]
-            loss = cal_loss(P2, label, weit)
-            for it in range(len(P1)):
-                loss = loss + (0.2 * it) * losses[it]
+            embedding1, P1, P2 = self._run(input, depth, x_hp, lowres=True)
+            # sum_it 0.2*it*cal_loss(P1[it]) + cal_loss(P2) (cod.py:137-142), up-sampling fused into the loss kernel
+            loss = ops.seg_loss([*P1, P2], label, weights=(0.0, 0.2, 0.4, 0.6, 1.0))
             with torch.no_grad():
                 e = (embedding1 - embedding1.min()) / (embedding1.max() - embedding1.min() + 1e-8)
                 loss3 = ssim_value(e, input.float())
             return {"loss": loss + loss3}
+        embedding1, P1, P2 = self._run(input, depth, x_hp)
         if mode == "predict":  # cod.py:152-153 + :219 (the PNG dumps of cod.py:156-217 are dropped)
             out = F.interpolate(P1[-1] + P2, size=label.shape[-2:], mode="bilinear", align_corners=False)
             return out.sigmoid(), label

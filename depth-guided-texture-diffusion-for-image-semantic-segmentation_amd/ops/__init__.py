@@ -6,3 +6,4 @@ from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401
 from .dwconv import dwconv_nhwc  # noqa: F401
 from .elementwise import colsum, linear, scale_residual  # noqa: F401
+from .loss import seg_loss  # noqa: F401

@@ -91,6 +91,18 @@ int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const 
 /* out fp32 [C] = column sums of x [rows, C]: the bias gradient of nn.Linear (cod.py:829,832,872-875,1097,1099).        */
 int dgtd_colsum(const void* x, float* out, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st);
 
+/* ---- Fused structure loss of the five deep-supervision heads (fp32) -------------------------------
+ * loss = sum_k mix[k] * cal_loss(bilinear_x(S/hs)(lo[k]), label): twig/model/cod.py:76-85 (weighted BCE + weighted IoU with
+ * weit = 1 + 5|avgpool31(gt) - gt|), :137-142 (mix = 0, .2, .4, .6 for P1[0..3], 1 for P2) and the x8 align_corners=False
+ * up-sampling of cod.py:796, :806.  lo [5,B,hs,hs] low-res logits; label [B,1,S,S]; mix [5]; loss [1].
+ * workspace (dgtd_seg_loss_workspace bytes) carries the weight map and the per-(map, sample) sums to the backward.   */
+int64_t dgtd_seg_loss_workspace(int B, int S);
+int dgtd_seg_loss_fwd(const float* lo, const float* label, const float* mix, float* loss, void* workspace,
+                      int B, int S, int hs, dgtd_stream s);
+/* dlo [5,B,hs,hs] overwritten = gout[0] * d loss / d lo.                                                                */
+int dgtd_seg_loss_bwd(const float* lo, const float* label, const float* mix, const float* gout, float* dlo,
+                      const void* workspace, int B, int S, int hs, dgtd_stream s);
+
 /* ---- Texture diffuser front end (fp32) -------------------------------------------------------
  * replaces twig/model/cod.py:1295-1298 (nearest 12x12 sample of the FFT high-pass image, 1x1 conv 3->1176,
  * sigmoid; depth 1x1 conv 1->24 + bilinear to 12x12) and MessagePassing.forward cod.py:1193-1205
