@@ -181,3 +181,23 @@ def test_linear_with_colsum_bias_grad(dgtd, rows, K, N, dtype):
     assert (gots[2].float() - wants[2]).norm() / wants[2].norm() < (1e-5 if dtype == torch.float32 else 2e-2)
     cs = dgtd.ops.colsum(dy.reshape(-1, N))
     torch.testing.assert_close(cs, dy.float().reshape(-1, N).sum(0), atol=1e-3 if dtype == torch.float32 else 1e-2, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- fused structure loss
+@pytest.mark.parametrize("S,hs,B", [(64, 8, 2), (96, 12, 3), (512, 64, 2)])
+def test_seg_loss_vs_oracle(dgtd, S, hs, B):
+    from oracle import cod_cpu
+    g = torch.Generator().manual_seed(S)
+    maps = [(torch.randn(B, 1, hs, hs, generator=g) * 2).requires_grad_() for _ in range(5)]
+    lo = torch.rand(B, 1, max(S // 16, 2), max(S // 16, 2), generator=g)
+    label = (F.interpolate(lo, size=(S, S), mode="bilinear") > 0.5).float()
+    mix = (0.0, 0.2, 0.4, 0.6, 1.0)
+    up = [F.interpolate(m, scale_factor=S // hs, mode="bilinear", align_corners=False) for m in maps]
+    want = sum(w * cod_cpu.cal_loss(u, label) for w, u in zip(mix, up))
+    gw = torch.autograd.grad(want, maps)
+    dev = [m.detach().cuda().requires_grad_() for m in maps]
+    got = dgtd.ops.seg_loss(dev, label.cuda(), mix)
+    gg = torch.autograd.grad(got * 1.5, dev)   # non-unit upstream gradient
+    assert abs(got.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
+    for a, b, w in zip(gg, gw, mix):
+        torch.testing.assert_close(a.cpu() / 1.5, b, atol=2e-7, rtol=2e-4)
