@@ -1,0 +1,259 @@
+// bindings.cpp — torch C++ autograd bindings over the C ABI of libdgtd.so (include/dgtd.h).
+// Same role as the reference's twig/ops/src/vision.cpp + functions/ms_deform_attn_func.py: tensors in, the C ABI called with raw
+// pointers on the current HIP stream, one autograd node per op.  Host plumbing only (no device code here): it exists because the
+// training step is host-bound in eager Python (~1600 Python autograd.Function calls per step); these nodes cost a few microseconds.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/autograd.h>
+#include <torch/library.h>
+
+#include "../../include/dgtd.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+inline void* stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+inline dgtd_dtype code(const Tensor& t) {
+  if (t.scalar_type() == at::kFloat) return DGTD_F32;
+  if (t.scalar_type() == at::kBFloat16) return DGTD_BF16;
+  TORCH_CHECK(false, "dgtd kernels take float32 or bfloat16 tensors, got ", t.scalar_type());
+}
+inline void check(int rc, const char* name) { TORCH_CHECK(rc == 0, name, " failed (code ", rc, "): ", dgtd_last_error()); }
+inline void on_device(const Tensor& t) { TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "dgtd ops need contiguous tensors on the HIP device"); }
+inline Tensor f32(const Tensor& t) { return t.scalar_type() == at::kFloat ? t.contiguous() : t.to(at::kFloat).contiguous(); }
+inline Tensor undefined() { return Tensor(); }
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w, const Tensor& b, double eps) {
+    Tensor x = x_.contiguous();
+    on_device(x);
+    const int64_t C = x.size(-1), rows = x.numel() / C;
+    Tensor w32 = f32(w), b32 = f32(b);
+    Tensor y = at::empty_like(x);
+    Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
+    check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
+                             stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
+    ctx->save_for_backward({x, w32, stats});
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w32 = saved[1], &stats = saved[2];
+    const int64_t C = x.size(-1), rows = x.numel() / C;
+    Tensor dy = g[0].contiguous();
+    if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
+    Tensor dx = at::empty_like(x);
+    Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
+    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C)}, x.options().dtype(at::kByte));
+    check(dgtd_layernorm_bwd(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                             dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C, ws.data_ptr(), rows, (int)C, code(x), stream()),
+          "dgtd_layernorm_bwd");
+    return {dx, dgb[0], dgb[1], undefined()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ SRA attention
+struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& q_, const Tensor& kv_, int64_t heads, double scale) {
+    Tensor q = q_.contiguous(), kv = kv_.contiguous();
+    on_device(q); on_device(kv);
+    const int64_t B = q.size(0), N = q.size(1), C = q.size(2), Nkv = kv.size(1);
+    TORCH_CHECK(C == heads * 64 && kv.size(2) == 2 * C && kv.scalar_type() == q.scalar_type(), "sra_attention: bad shapes");
+    Tensor out = at::empty_like(q);
+    Tensor lse = at::empty({B, heads, N}, q.options().dtype(at::kFloat));
+    check(dgtd_sra_attn_fwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)N, (int)Nkv, (int)heads,
+                            (float)scale, code(q), stream()), "dgtd_sra_attn_fwd");
+    ctx->save_for_backward({q, kv, out, lse});
+    ctx->saved_data["heads"] = heads;
+    ctx->saved_data["scale"] = scale;
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &q = saved[0], &kv = saved[1], &out = saved[2], &lse = saved[3];
+    const int64_t heads = ctx->saved_data["heads"].toInt();
+    const double scale = ctx->saved_data["scale"].toDouble();
+    const int64_t B = q.size(0), N = q.size(1), Nkv = kv.size(1);
+    Tensor dout = g[0].contiguous();
+    if (dout.scalar_type() != q.scalar_type()) dout = dout.to(q.scalar_type());
+    Tensor dq = at::empty_like(q);
+    Tensor dkv = at::zeros(kv.sizes(), kv.options().dtype(at::kFloat));
+    Tensor ws = at::empty({dgtd_sra_attn_bwd_workspace((int)B, (int)N, (int)heads)}, q.options().dtype(at::kByte));
+    check(dgtd_sra_attn_bwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dq.data_ptr(),
+                            dkv.data_ptr<float>(), ws.data_ptr(), (int)B, (int)N, (int)Nkv, (int)heads, (float)scale, code(q), stream()),
+          "dgtd_sra_attn_bwd");
+    return {dq, dkv.to(kv.scalar_type()), undefined(), undefined()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ depthwise conv (NHWC)
+struct DwConvFn : public torch::autograd::Function<DwConvFn> {
+  static Tensor launch(const Tensor& x, const float* wt, const float* bias, const Tensor* aux, int mode, int K) {
+    Tensor y = at::empty_like(x);
+    check(dgtd_dwconv_fwd(x.data_ptr(), wt, bias, aux ? aux->data_ptr() : nullptr, y.data_ptr(), (int)x.size(0), (int)x.size(1),
+                          (int)x.size(2), (int)x.size(3), K, mode, code(x), stream()), "dgtd_dwconv_fwd");
+    return y;
+  }
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& weight_, const c10::optional<Tensor>& bias_, bool gelu) {
+    Tensor x = x_.contiguous(), weight = weight_.contiguous();
+    on_device(x); on_device(weight);
+    const int64_t C = weight.size(0), K = weight.size(3), KK = K * K;
+    const bool has_bias = bias_.has_value() && bias_->defined();
+    TORCH_CHECK(x.size(3) == C && weight.size(1) == 1, "dwconv_nhwc: bad shapes");
+    Tensor bias = has_bias ? bias_->contiguous() : Tensor();
+    if (has_bias) TORCH_CHECK(bias.scalar_type() == weight.scalar_type(), "dwconv_nhwc: weight/bias dtype mismatch");
+    Tensor packed = at::empty({(2 * KK + 1) * C}, x.options().dtype(at::kFloat));   // { w_t | w_t flipped | bias }
+    check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight),
+                           stream()), "dgtd_dwconv_pack");
+    const float* base = packed.data_ptr<float>();
+    Tensor y = launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, gelu ? 1 : 0, (int)K);
+    ctx->save_for_backward({x, packed});
+    ctx->saved_data["gelu"] = gelu;
+    ctx->saved_data["K"] = K;
+    ctx->saved_data["has_bias"] = has_bias;
+    ctx->saved_data["bf16_w"] = weight.scalar_type() == at::kBFloat16;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &packed = saved[1];
+    const bool gelu = ctx->saved_data["gelu"].toBool(), has_bias = ctx->saved_data["has_bias"].toBool();
+    const int64_t K = ctx->saved_data["K"].toInt(), KK = K * K, C = x.size(3);
+    const auto wdtype = ctx->saved_data["bf16_w"].toBool() ? at::kBFloat16 : at::kFloat;
+    Tensor dy = g[0].contiguous();
+    if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
+    const float* base = packed.data_ptr<float>();
+    const float* bias = has_bias ? base + 2 * KK * C : nullptr;
+    Tensor du = gelu ? launch(x, base, bias, &dy, 2, (int)K) : dy;          // through the GELU: recompute the pre-activation
+    Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);     // bwd-data = same kernel, flipped filter
+    Tensor grads = at::zeros({(KK + 1) * C}, x.options().dtype(at::kFloat));
+    float* gb = grads.data_ptr<float>();
+    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? gb + KK * C : nullptr, (int)x.size(0), (int)x.size(1),
+                                 (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");
+    Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
+    Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
+    check(dgtd_dwconv_unpack_grads(gb, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int)C, (int)K, code(dw), stream()),
+          "dgtd_dwconv_unpack_grads");
+    return {dx, dw, db, undefined()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ x + s[b]*gamma[c]*y
+struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& y_, const c10::optional<Tensor>& s_, const c10::optional<Tensor>& gamma_) {
+    Tensor x = x_.contiguous(), y = y_.scalar_type() == x_.scalar_type() ? y_.contiguous() : y_.to(x_.scalar_type()).contiguous();
+    on_device(x);
+    const bool has_s = s_.has_value() && s_->defined(), has_g = gamma_.has_value() && gamma_->defined();
+    const int64_t B = x.size(0), C = x.size(-1), rows = x.numel() / C;
+    Tensor s = has_s ? f32(*s_) : Tensor(), g32 = has_g ? f32(*gamma_) : Tensor();
+    Tensor out = at::empty_like(x);
+    check(dgtd_scale_residual_fwd(x.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                  out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
+    ctx->save_for_backward({y, s, g32});
+    ctx->saved_data["has_s"] = has_s;
+    ctx->saved_data["has_g"] = has_g;
+    ctx->saved_data["bf16_g"] = has_g && gamma_->scalar_type() == at::kBFloat16;
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &y = saved[0], &s = saved[1], &g32 = saved[2];
+    const bool has_s = ctx->saved_data["has_s"].toBool(), has_g = ctx->saved_data["has_g"].toBool();
+    Tensor g = gr[0].contiguous();
+    if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
+    if (!has_s && !has_g) return {g, g, undefined(), undefined()};
+    const int64_t B = y.size(0), C = y.size(-1), rows = y.numel() / C;
+    Tensor dy = at::empty_like(y);
+    Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
+    Tensor ws = has_g ? at::empty({dgtd_colsum_workspace((int)C)}, y.options().dtype(at::kByte)) : Tensor();
+    check(dgtd_scale_residual_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                  dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, has_g ? ws.data_ptr() : nullptr, rows, (int)C,
+                                  rows / B, code(y), stream()), "dgtd_scale_residual_bwd");
+    if (has_g && ctx->saved_data["bf16_g"].toBool()) dgamma = dgamma.to(at::kBFloat16);
+    return {g, dy, undefined(), dgamma};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ Linear (library GEMMs + colsum bias grad)
+Tensor colsum(const Tensor& x2) {
+  const int64_t rows = x2.size(0), C = x2.size(1);
+  Tensor out = at::empty({C}, x2.options().dtype(at::kFloat));
+  Tensor ws = at::empty({dgtd_colsum_workspace((int)C)}, x2.options().dtype(at::kByte));
+  check(dgtd_colsum(x2.data_ptr(), out.data_ptr<float>(), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
+  return out;
+}
+
+struct LinearFn : public torch::autograd::Function<LinearFn> {
+  // compute dtype `dt` is decided by the caller (autocast policy lives in Python)
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b_, int64_t dt_code) {
+    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    const bool has_b = b_.has_value() && b_->defined();
+    Tensor x2 = x.reshape({-1, x.size(-1)});
+    if (x2.scalar_type() != dt) x2 = x2.to(dt);
+    Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
+    std::vector<int64_t> oshape(x.sizes().begin(), x.sizes().end());
+    oshape.back() = w.size(0);
+    Tensor out = at::empty(oshape, x.options().dtype(dt));
+    Tensor o2 = out.view({-1, w.size(0)});
+    if (has_b) {
+      Tensor bc = b_->scalar_type() == dt ? *b_ : b_->to(dt);
+      at::addmm_out(o2, bc, x2, wc.t());
+    } else {
+      at::mm_out(o2, x2, wc.t());
+    }
+    ctx->save_for_backward({x2, wc});
+    ctx->saved_data["xshape"] = x.sizes().vec();
+    ctx->saved_data["w_bf16"] = w.scalar_type() == at::kBFloat16;
+    ctx->saved_data["b_kind"] = has_b ? (b_->scalar_type() == at::kBFloat16 ? 2 : 1) : 0;
+    ctx->saved_data["need_dx"] = x.requires_grad();
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x2 = saved[0], &wc = saved[1];
+    Tensor dy2 = g[0].reshape({-1, g[0].size(-1)});
+    if (dy2.scalar_type() != x2.scalar_type()) dy2 = dy2.to(x2.scalar_type());
+    dy2 = dy2.contiguous();
+    Tensor dx;
+    if (ctx->saved_data["need_dx"].toBool()) dx = at::mm(dy2, wc).view(ctx->saved_data["xshape"].toIntVector());
+    // dW = dY^T X; long token dimensions are split into S batches (library batched GEMM) and summed in fp32: the plain GEMM has
+    // only a few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
+    const int64_t M = dy2.size(0);
+    const int64_t S = std::min<int64_t>(32, M / 1024);
+    Tensor dw;
+    if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
+      Tensor part = at::bmm(dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
+      dw = at::sum(part, {0}, false, at::kFloat).to(dy2.scalar_type());
+    } else {
+      dw = at::mm(dy2.t(), x2);
+    }
+    const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
+    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
+    Tensor db;
+    const int64_t bk = ctx->saved_data["b_kind"].toInt();
+    if (bk) { db = colsum(dy2); if (bk == 2) db = db.to(at::kBFloat16); }
+    return {dx, dw, db, undefined()};
+  }
+};
+
+Tensor layer_norm(const Tensor& x, const Tensor& w, const Tensor& b, double eps) { return LayerNormFn::apply(x, w, b, eps); }
+Tensor sra_attention(const Tensor& q, const Tensor& kv, int64_t heads, double scale) { return SraAttnFn::apply(q, kv, heads, scale); }
+Tensor dwconv_nhwc(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool gelu) { return DwConvFn::apply(x, w, b, gelu); }
+Tensor scale_residual(const Tensor& x, const Tensor& y, const c10::optional<Tensor>& s, const c10::optional<Tensor>& gamma) {
+  return ScaleResidualFn::apply(x, y, s, gamma);
+}
+Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t dt_code) { return LinearFn::apply(x, w, b, dt_code); }
+
+}  // namespace
+
+TORCH_LIBRARY(dgtd, m) {
+  m.def("layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", &layer_norm);
+  m.def("sra_attention(Tensor q, Tensor kv, int heads, float scale) -> Tensor", &sra_attention);
+  m.def("dwconv_nhwc(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> Tensor", &dwconv_nhwc);
+  m.def("scale_residual(Tensor x, Tensor y, Tensor? s, Tensor? gamma) -> Tensor", &scale_residual);
+  m.def("linear(Tensor x, Tensor weight, Tensor? bias, int dtype_code) -> Tensor", &linear);
+}

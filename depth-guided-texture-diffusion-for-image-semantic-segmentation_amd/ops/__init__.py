@@ -1,6 +1,7 @@
 """torch.autograd.Function wrappers over the C ABI — the same pattern as the reference's own native op
 (twig/ops/functions/ms_deform_attn_func.py:19-46): forward saves its inputs, backward is
 once_differentiable and returns one gradient per input."""
+from . import _native  # noqa: F401
 from .layernorm import layer_norm  # noqa: F401
 from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401

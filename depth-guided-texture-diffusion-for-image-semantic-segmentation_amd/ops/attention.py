@@ -5,6 +5,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 
 class _SraAttnFn(Function):
@@ -45,4 +46,7 @@ class _SraAttnFn(Function):
 
 
 def sra_attention(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    nat = _native.ops()
+    if nat is not None and q.is_cuda:
+        return nat.sra_attention(q, kv, heads, float(scale))
     return _SraAttnFn.apply(q.contiguous(), kv.contiguous(), heads, scale)

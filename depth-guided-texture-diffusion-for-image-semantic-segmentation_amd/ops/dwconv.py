@@ -5,6 +5,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 
 def _launch_fwd(x, wt_ptr, bias_ptr, aux, mode, K):
@@ -60,4 +61,7 @@ class _DwConvFn(Function):
 
 
 def dwconv_nhwc(x: torch.Tensor, weight: torch.Tensor, bias, gelu: bool = False) -> torch.Tensor:
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.dwconv_nhwc(x, weight, bias, bool(gelu))
     return _DwConvFn.apply(x.contiguous(), weight.contiguous(), bias, gelu)

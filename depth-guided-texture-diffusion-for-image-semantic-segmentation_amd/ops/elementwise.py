@@ -7,6 +7,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 _WS = {}
 SPLITK_WGRAD = os.environ.get("DGTD_SPLITK_WGRAD", "1") != "0"   # A/B switch for tools/ and bench runs
@@ -75,6 +76,9 @@ class _ScaleResidualFn(Function):
 def scale_residual(x, y, s=None, gamma=None):
     if s is None and gamma is None:
         return x + y
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.scale_residual(x, y, s, gamma)
     if y.dtype != x.dtype:
         y = y.to(x.dtype)
     return _ScaleResidualFn.apply(x.contiguous(), y.contiguous(), s, gamma)
@@ -133,4 +137,10 @@ class _LinearFn(Function):
 
 
 def linear(x, w, b=None):
+    nat = _native.ops()
+    if nat is not None and x.is_cuda and SPLITK_WGRAD:
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if dt in (torch.float32, torch.bfloat16):
+            with torch.autocast("cuda", enabled=False):
+                return nat.linear(x, w, b, 1 if dt == torch.bfloat16 else 0)
     return _LinearFn.apply(x, w, b)

@@ -5,6 +5,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 
 class _LayerNormFn(Function):
@@ -45,4 +46,7 @@ class _LayerNormFn(Function):
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.layer_norm(x, weight, bias, eps)
     return _LayerNormFn.apply(x.contiguous(), weight, bias, eps)

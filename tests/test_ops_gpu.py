@@ -8,11 +8,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dgtd():
+@pytest.fixture(scope="module", params=["python-bindings", "cpp-bindings"])
+def dgtd(request):
+    """Every op test runs through both host binding layers over the same C ABI: the Python autograd.Functions and the
+    C++ torch bindings (libdgtd_torch.so)."""
     import dgtd as m
     m._lib.load()
-    return m
+    old = m.ops._native.ENABLED
+    m.ops._native.ENABLED = request.param == "cpp-bindings"
+    if m.ops._native.ENABLED:
+        assert m.ops._native.ops() is not None, "libdgtd_torch.so missing: run python __graft_entry__.py"
+    yield m
+    m.ops._native.ENABLED = old
 
 
 def _rand(*shape, seed=0, dtype=torch.float32, scale=1.0):
