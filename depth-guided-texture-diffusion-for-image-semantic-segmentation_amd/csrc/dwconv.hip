@@ -102,9 +102,30 @@ template <typename T> struct Pair;
 template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Pair<bf16_t> { typedef bf16_t type __attribute__((ext_vector_type(2))); };
 
+// ws[gridDim.x][K*K + 1][C] -> out[(K*K + 1) * C] (= { dw_t | db }); fixed summation order, no atomics
+__global__ __launch_bounds__(256) void dwconv_bww_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks,
+                                                                int ncols) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < ncols) {
+    const float* p = ws + col;
+    int b = wave;
+    for (; b + 12 < nblocks; b += 16) {
+      const float v0 = p[(size_t)b * ncols], v1 = p[(size_t)(b + 4) * ncols], v2 = p[(size_t)(b + 8) * ncols], v3 = p[(size_t)(b + 12) * ncols];
+      s0 += v0 + v1; s1 += v2 + v3;
+    }
+    for (; b < nblocks; b += 4) s0 += p[(size_t)b * ncols];
+  }
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && col < ncols) out[col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
 template <typename T, int K, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
-                                                                float* __restrict__ dwt, float* __restrict__ db,
+                                                                float* __restrict__ ws, int has_bias,
                                                                 int B, int H, int W, int C) {
   // blockIdx.y = 128-channel block, blockIdx.z = filter row ky: K accumulators x 2 channels per lane, so the kernel runs at
   // full occupancy and K times more waves are in flight than with a whole-filter accumulator.
@@ -164,11 +185,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   for (int t = 0; t < K; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
   if (ky == P) { atomicAdd(&red[K][lane * 2], accb[0]); atomicAdd(&red[K][lane * 2 + 1], accb[1]); }
   __syncthreads();
+  // this workgroup's partial rows go to ws[blockIdx.x][row][C] with plain stores (many workgroups atomically adding into the
+  // same few hundred addresses run in the 14x-slow contended regime of the memory-side atomics)
+  float* wsb = ws + (size_t)blockIdx.x * (K * K + 1) * C + blockIdx.y * 128;
   for (int i = tid; i < (K + 1) * 128; i += 256) {
     const int t = i >> 7, c = i & 127;
-    const float v = red[t][c];
-    if (t < K) atomicAdd(&dwt[(size_t)(ky * K + t) * C + blockIdx.y * 128 + c], v);
-    else if (db && ky == P) atomicAdd(&db[blockIdx.y * 128 + c], v);
+    if (t < K) wsb[(size_t)(ky * K + t) * C + c] = red[t][c];
+    else if (ky == P) wsb[(size_t)(K * K) * C + c] = has_bias ? red[K][c] : 0.f;
   }
 }
 
@@ -211,15 +234,23 @@ int fwd_launch(const void* x, const float* wt, const float* bias, const void* au
   return 0;
 }
 
+static int bww_gx(int64_t nstrips, int ncb, int K) {
+  // ~2048 workgroups in total, >= 4 strips per wave
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 2048 / (ncb * K))));
+}
+
 template <typename T, int K, int TX>
-int bww_launch(const void* x, const void* du, float* dwt, float* db, int B, int H, int W, int C, hipStream_t s) {
+int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, hipStream_t s) {
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
   const int ncb = C / 128;
   const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
-  // every workgroup pays a fixed (K+1)*128-float LDS zero + global-atomic flush: ~2048 workgroups in total, >= 4 strips per wave
-  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 2048 / (ncb * K))));
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb, K), dim3(256), 0, s, (const T*)x, (const T*)du, dwt, db, B, H, W, C);
+  const int gx = bww_gx(nstrips, ncb, K);
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb, K), dim3(256), 0, s, (const T*)x, (const T*)du, (float*)workspace,
+                     has_bias, B, H, W, C);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
+  const int ncols = (K * K + 1) * C;
+  hipLaunchKernelGGL(dwconv_bww_reduce_kernel, dim3((int)cdiv(ncols, 64)), dim3(256), 0, s, (const float*)workspace, grads, gx, ncols);
+  DGTD_CHECK_LAUNCH("dwconv_bww_reduce");
   return 0;
 }
 
@@ -231,20 +262,28 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
   DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
-  if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
-                                     : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
-  if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
-                                    : fwd_launch<float, 4, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                     : fwd_launch<bf16_t, 8, 3, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                    : fwd_launch<float, 4, 3, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   DGTD_FAIL(2, "dwconv_fwd: bad dtype %d", (int)dt);
 }
 
-extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* dw_t, float* db, int B, int H, int W, int C, int K,
-                                      dgtd_dtype dt, dgtd_stream s) {
+extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int C, int K) {
+  const int ncb = std::max(1, C / 128);
+  const int gx = std::max(1, 2048 / (ncb * K));
+  return (int64_t)gx * (K * K + 1) * C * sizeof(float);
+}
+
+extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W,
+                                      int C, int K, dgtd_dtype dt, dgtd_stream s) {
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight: K=%d (only 3 and 7 are on the path)", K);
   hipStream_t st = (hipStream_t)s;
-  if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<bf16_t, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
-  if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, dw_t, db, B, H, W, C, st) : bww_launch<float, 3, 8>(x, du, dw_t, db, B, H, W, C, st);
+  if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
+                                     : bww_launch<bf16_t, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
+  if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
+                                    : bww_launch<float, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   DGTD_FAIL(2, "dwconv_bwd_weight: bad dtype %d", (int)dt);
 }
 

@@ -130,9 +130,10 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     const float* bias = has_bias ? base + 2 * KK * C : nullptr;
     Tensor du = gelu ? launch(x, base, bias, &dy, 2, (int)K) : dy;          // through the GELU: recompute the pre-activation
     Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);     // bwd-data = same kernel, flipped filter
-    Tensor grads = at::zeros({(KK + 1) * C}, x.options().dtype(at::kFloat));
+    Tensor grads = at::empty({(KK + 1) * C}, x.options().dtype(at::kFloat));
+    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)C, (int)K)}, x.options().dtype(at::kByte));
     float* gb = grads.data_ptr<float>();
-    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? gb + KK * C : nullptr, (int)x.size(0), (int)x.size(1),
+    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1),
                                  (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
