@@ -262,10 +262,10 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
   DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
-  if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
-                                     : fwd_launch<bf16_t, 8, 3, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
-  if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
-                                    : fwd_launch<float, 4, 3, 8>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                     : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                    : fwd_launch<float, 4, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   DGTD_FAIL(2, "dwconv_fwd: bad dtype %d", (int)dt);
 }
 
