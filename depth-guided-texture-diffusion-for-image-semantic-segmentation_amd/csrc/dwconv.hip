@@ -127,21 +127,22 @@ template <typename T, int K, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
                                                                 float* __restrict__ ws, int has_bias,
                                                                 int B, int H, int W, int C) {
-  // blockIdx.y = 128-channel block, blockIdx.z = filter row ky: K accumulators x 2 channels per lane, so the kernel runs at
-  // full occupancy and K times more waves are in flight than with a whole-filter accumulator.
+  // blockIdx.x = filter row ky (FASTEST index: the K workgroups that sweep the same strips are dispatched together and share
+  // their input rows in L2 instead of re-streaming the tensor once per filter row), blockIdx.y = 128-channel block,
+  // blockIdx.z = strip group.  K accumulators x 2 channels per lane -> full occupancy.
   typedef typename Pair<T>::type PT;
   constexpr int P = K / 2;
   __shared__ float red[K + 1][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.y * 128 + lane * 2;
-  const int ky = blockIdx.z;
+  const int ky = blockIdx.x;
   const int XB = (W + TX - 1) / TX;
   const int64_t nstrips = (int64_t)B * H * XB;
   for (int i = tid; i < (K + 1) * 128; i += 256) (&red[0][0])[i] = 0.f;
   float acc[K][2], accb[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < K; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < nstrips; s += (int64_t)gridDim.x * 4) {
+  for (int64_t s = (int64_t)blockIdx.z * 4 + wave; s < nstrips; s += (int64_t)gridDim.z * 4) {
     int64_t r = s;
     const int xb = (int)(r % XB); r /= XB;
     const int yy0 = (int)(r % H);
@@ -185,9 +186,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   for (int t = 0; t < K; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
   if (ky == P) { atomicAdd(&red[K][lane * 2], accb[0]); atomicAdd(&red[K][lane * 2 + 1], accb[1]); }
   __syncthreads();
-  // this workgroup's partial rows go to ws[blockIdx.x][row][C] with plain stores (many workgroups atomically adding into the
+  // this workgroup's partial rows go to ws[blockIdx.z][row][C] with plain stores (many workgroups atomically adding into the
   // same few hundred addresses run in the 14x-slow contended regime of the memory-side atomics)
-  float* wsb = ws + (size_t)blockIdx.x * (K * K + 1) * C + blockIdx.y * 128;
+  float* wsb = ws + (size_t)blockIdx.z * (K * K + 1) * C + blockIdx.y * 128;
   for (int i = tid; i < (K + 1) * 128; i += 256) {
     const int t = i >> 7, c = i & 127;
     if (t < K) wsb[(size_t)(ky * K + t) * C + c] = red[t][c];
@@ -245,7 +246,7 @@ int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* 
   const int ncb = C / 128;
   const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
   const int gx = bww_gx(nstrips, ncb, K);
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb, K), dim3(256), 0, s, (const T*)x, (const T*)du, (float*)workspace,
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(K, ncb, gx), dim3(256), 0, s, (const T*)x, (const T*)du, (float*)workspace,
                      has_bias, B, H, W, C);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
   const int ncols = (K * K + 1) * C;
