@@ -27,7 +27,7 @@ SIGNATURES = {
     "dgtd_sra_attn_bwd_workspace": (_i64, [_i, _i, _i]),
     "dgtd_sra_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _fp, _vp, _fp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dgtd_dwconv_fwd": (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "dgtd_dwconv_bwd_weight_workspace": (_i64, [_i, _i]),
+    "dgtd_dwconv_bwd_weight_workspace": (_i64, [_i, _i, _i, _i, _i]),
     "dgtd_dwconv_bwd_weight": (_i, [_vp, _vp, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_dwconv_pack": (_i, [_vp, _vp, _fp, _i, _i, _i, _vp]),
     "dgtd_dwconv_unpack_grads": (_i, [_fp, _vp, _vp, _i, _i, _i, _vp]),

@@ -30,7 +30,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   constexpr int P = K / 2;
   const int CV = C / V, XB = (W + TX - 1) / TX;
   const int64_t total = (int64_t)B * H * XB * CV;
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+  // XCD-aware block remap (guide T1): hardware deals consecutive block ids round-robin over the 8 XCDs, so logically adjacent
+  // tiles (the next rows of the same band, which re-read K-1 of the same input rows) would never share an L2.  Give every XCD a
+  // contiguous range of logical blocks instead (bijective for any grid size).
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, qn = nb >> 3, rn = nb & 7;
+  const int lbid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+  for (int64_t gid = (int64_t)lbid * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
     const int cv = (int)(gid % CV);
     int64_t strip = gid / CV;
     const int xb = (int)(strip % XB); strip /= XB;
@@ -123,33 +128,33 @@ __global__ __launch_bounds__(256) void dwconv_bww_reduce_kernel(const float* __r
   if (wave == 0 && col < ncols) out[col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
+// One workgroup = K waves; wave w owns filter row ky = w.  All K waves walk the SAME column of strips (fixed image, x-range and
+// 128-channel block; y ascending), so the gradient strip and K-1 of the K input rows each wave needs were just fetched by a
+// sibling wave on the same CU: the K-fold row reuse is served by that CU's L1 instead of L2/MALL.  A wave keeps K accumulators x
+// 2 channels per lane and writes its own K x 128 partial rows at the end (no cross-wave reduction; the bias row comes from the
+// centre wave); partials of all workgroups are summed by dwconv_bww_reduce_kernel in a fixed order.
 template <typename T, int K, int TX>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
-                                                                float* __restrict__ ws, int has_bias,
-                                                                int B, int H, int W, int C) {
-  // blockIdx.x = filter row ky (FASTEST index: the K workgroups that sweep the same strips are dispatched together and share
-  // their input rows in L2 instead of re-streaming the tensor once per filter row), blockIdx.y = 128-channel block,
-  // blockIdx.z = strip group.  K accumulators x 2 channels per lane -> full occupancy.
+__global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ du,
+                                                                   float* __restrict__ ws, int has_bias,
+                                                                   int B, int H, int W, int C, int ysplit) {
   typedef typename Pair<T>::type PT;
   constexpr int P = K / 2;
-  __shared__ float red[K + 1][128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;
   const int c0 = blockIdx.y * 128 + lane * 2;
-  const int ky = blockIdx.x;
   const int XB = (W + TX - 1) / TX;
-  const int64_t nstrips = (int64_t)B * H * XB;
-  for (int i = tid; i < (K + 1) * 128; i += 256) (&red[0][0])[i] = 0.f;
+  // blockIdx.x enumerates (b, xb, ypart); XCD-aware remap keeps the parts of one column on one XCD
+  const int nbx = gridDim.x, xcd = blockIdx.x & 7, qn = nbx >> 3, rn = nbx & 7;
+  const int col = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+  const int ypart = col % ysplit, xb = (col / ysplit) % XB, b = col / (ysplit * XB);
+  const int rows_per = (H + ysplit - 1) / ysplit;
+  const int y_begin = ypart * rows_per, y_end = min(H, y_begin + rows_per);
+  const int x0 = xb * TX;
   float acc[K][2], accb[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < K; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
-  for (int64_t s = (int64_t)blockIdx.z * 4 + wave; s < nstrips; s += (int64_t)gridDim.z * 4) {
-    int64_t r = s;
-    const int xb = (int)(r % XB); r /= XB;
-    const int yy0 = (int)(r % H);
-    const int b = (int)(r / H);
-    const int x0 = xb * TX;
+  for (int yy0 = y_begin; yy0 < y_end; ++yy0) {
     const int yy = yy0 + ky - P;
-    if (yy < 0 || yy >= H) continue;
+    if (yy < 0 || yy >= H) continue;                 // wave-uniform
     float g[TX][2];
     const T* grow = du + (((size_t)b * H + yy0) * W) * C + c0;
     const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
@@ -181,45 +186,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
         acc[kx][1] += g[t][1] * in[t + kx][1];
       }
   }
-  __syncthreads();
+  // ws[blockIdx.x][K*K + 1][C]: this wave's K tap rows (+ the bias row from the centre wave), plain 8-byte stores
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float* wsb = ws + (size_t)blockIdx.x * (K * K + 1) * C + c0;
 #pragma unroll
-  for (int t = 0; t < K; ++t) { atomicAdd(&red[t][lane * 2], acc[t][0]); atomicAdd(&red[t][lane * 2 + 1], acc[t][1]); }
-  if (ky == P) { atomicAdd(&red[K][lane * 2], accb[0]); atomicAdd(&red[K][lane * 2 + 1], accb[1]); }
-  __syncthreads();
-  // this workgroup's partial rows go to ws[blockIdx.z][row][C] with plain stores (many workgroups atomically adding into the
-  // same few hundred addresses run in the 14x-slow contended regime of the memory-side atomics)
-  float* wsb = ws + (size_t)blockIdx.z * (K * K + 1) * C + blockIdx.y * 128;
-  for (int i = tid; i < (K + 1) * 128; i += 256) {
-    const int t = i >> 7, c = i & 127;
-    if (t < K) wsb[(size_t)(ky * K + t) * C + c] = red[t][c];
-    else if (ky == P) wsb[(size_t)(K * K) * C + c] = has_bias ? red[K][c] : 0.f;
-  }
-}
-
-// weights [C, K*K] (Conv2d layout, dtype T) + bias [C] -> packed fp32 [ wt (K*K x C) | wt spatially flipped | bias ]
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ w, const T* __restrict__ bias,
-                                                          float* __restrict__ packed, int C, int KK) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // i = t * C + c
-  if (i < KK * C) {
-    const int t = i / C, c = i % C;
-    const float v = (float)w[(size_t)c * KK + t];
-    packed[i] = v;
-    packed[(size_t)KK * C + (size_t)(KK - 1 - t) * C + c] = v;
-  }
-  if (i < C) packed[(size_t)2 * KK * C + i] = bias ? (float)bias[i] : 0.f;
-}
-
-// grads fp32 [ dwt (K*K x C) | db (C) ] -> dweight [C, K*K] and dbias [C] in dtype T
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_unpack_kernel(const float* __restrict__ g, T* __restrict__ dw,
-                                                            T* __restrict__ db, int C, int KK) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // i = c * KK + t
-  if (i < KK * C) {
-    const int c = i / KK, t = i % KK;
-    dw[i] = (T)g[(size_t)t * C + c];
-  }
-  if (db && i < C) db[i] = (T)g[(size_t)KK * C + i];
+  for (int t = 0; t < K; ++t) { f32x2 v; v[0] = acc[t][0]; v[1] = acc[t][1]; *reinterpret_cast<f32x2*>(wsb + (size_t)(ky * K + t) * C) = v; }
+  if (ky == P) { f32x2 v; v[0] = has_bias ? accb[0] : 0.f; v[1] = has_bias ? accb[1] : 0.f; *reinterpret_cast<f32x2*>(wsb + (size_t)(K * K) * C) = v; }
 }
 
 template <typename T, int V, int K, int TX>
@@ -235,19 +207,21 @@ int fwd_launch(const void* x, const float* wt, const float* bias, const void* au
   return 0;
 }
 
-static int bww_gx(int64_t nstrips, int ncb, int K) {
-  // ~2048 workgroups in total, >= 4 strips per wave
-  return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nstrips, 16), std::max(1, 2048 / (ncb * K))));
+// columns = B * ceil(W/TX) strip columns per channel block; split each column into `ysplit` row ranges until ~1024 workgroups exist
+static int bww_ysplit(int B, int H, int W, int C, int TX) {
+  const int64_t cols = (int64_t)B * cdiv(W, TX) * (C / 128);
+  int ys = 1;
+  while (ys < H && cols * ys < 1024 && (H / (ys * 2)) >= 4) ys *= 2;
+  return ys;
 }
 
 template <typename T, int K, int TX>
 int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, hipStream_t s) {
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
-  const int ncb = C / 128;
-  const int64_t nstrips = (int64_t)B * H * cdiv(W, TX);
-  const int gx = bww_gx(nstrips, ncb, K);
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(K, ncb, gx), dim3(256), 0, s, (const T*)x, (const T*)du, (float*)workspace,
-                     has_bias, B, H, W, C);
+  const int ncb = C / 128, ys = bww_ysplit(B, H, W, C, TX);
+  const int gx = B * (int)cdiv(W, TX) * ys;
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(K * 64), 0, s, (const T*)x, (const T*)du, (float*)workspace,
+                     has_bias, B, H, W, C, ys);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
   const int ncols = (K * K + 1) * C;
   hipLaunchKernelGGL(dwconv_bww_reduce_kernel, dim3((int)cdiv(ncols, 64)), dim3(256), 0, s, (const float*)workspace, grads, gx, ncols);
@@ -270,10 +244,9 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_FAIL(2, "dwconv_fwd: bad dtype %d", (int)dt);
 }
 
-extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int C, int K) {
-  const int ncb = std::max(1, C / 128);
-  const int gx = std::max(1, 2048 / (ncb * K));
-  return (int64_t)gx * (K * K + 1) * C * sizeof(float);
+extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K) {
+  const int ys = bww_ysplit(B, H, W, C, 8);
+  return (int64_t)B * cdiv(W, 8) * ys * (K * K + 1) * C * sizeof(float);
 }
 
 extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W,

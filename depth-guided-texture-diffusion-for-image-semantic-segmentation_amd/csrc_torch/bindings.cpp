@@ -131,7 +131,7 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     Tensor du = gelu ? launch(x, base, bias, &dy, 2, (int)K) : dy;          // through the GELU: recompute the pre-activation
     Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);     // bwd-data = same kernel, flipped filter
     Tensor grads = at::empty({(KK + 1) * C}, x.options().dtype(at::kFloat));
-    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)C, (int)K)}, x.options().dtype(at::kByte));
+    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K)}, x.options().dtype(at::kByte));
     float* gb = grads.data_ptr<float>();
     check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1),
                                  (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");

@@ -50,7 +50,7 @@ class _DwConvFn(Function):
         du = _launch_fwd(x, base, bias_ptr, dy, 2, K) if gelu else dy      # through the GELU: recompute the pre-activation
         dx = _launch_fwd(du, base + 4 * KK * C, None, None, 0, K)          # bwd-data = same kernel, flipped filter
         grads = torch.empty((KK + 1) * C, dtype=torch.float32, device=x.device)   # { dw_t | db }
-        ws = torch.empty(L.load().dgtd_dwconv_bwd_weight_workspace(C, K), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(L.load().dgtd_dwconv_bwd_weight_workspace(B, H, W, C, K), dtype=torch.uint8, device=x.device)
         gb = grads.data_ptr()
         L.call("dgtd_dwconv_bwd_weight", L.ptr(x), L.ptr(du), gb, 1 if has_bias else 0, L.ptr(ws), B, H, W, C, K,
                L.dtype_code(x), L.stream_ptr(), algo=("hbm", 2 * x.element_size() * x.numel()),

@@ -74,8 +74,8 @@ int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, int C, int 
 /* grads fp32 [(K*K + 1) * C] = { dw_t | db } -> dw [C,1,K,K], db [C] in dtype wdt (db may be NULL).           */
 int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int K, dgtd_dtype wdt, dgtd_stream s);
 /* grads fp32 [(K*K + 1) * C] = { dw_t | db } is OVERWRITTEN (db = 0 when has_bias == 0); C % 128 == 0.
- * workspace: dgtd_dwconv_bwd_weight_workspace(C, K) bytes (per-workgroup partial sums, reduced in a fixed order). */
-int64_t dgtd_dwconv_bwd_weight_workspace(int C, int K);
+ * workspace: dgtd_dwconv_bwd_weight_workspace(...) bytes (per-workgroup partial sums, reduced in a fixed order). */
+int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K);
 int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace,
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
 
