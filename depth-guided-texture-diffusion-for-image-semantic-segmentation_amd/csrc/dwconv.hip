@@ -194,6 +194,32 @@ __global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __re
   if (ky == P) { f32x2 v; v[0] = has_bias ? accb[0] : 0.f; v[1] = has_bias ? accb[1] : 0.f; *reinterpret_cast<f32x2*>(wsb + (size_t)(K * K) * C) = v; }
 }
 
+// weights [C, K*K] (Conv2d layout, dtype T) + bias [C] -> packed fp32 [ wt (K*K x C) | wt spatially flipped | bias ]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ w, const T* __restrict__ bias,
+                                                          float* __restrict__ packed, int C, int KK) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // i = t * C + c
+  if (i < KK * C) {
+    const int t = i / C, c = i % C;
+    const float v = (float)w[(size_t)c * KK + t];
+    packed[i] = v;
+    packed[(size_t)KK * C + (size_t)(KK - 1 - t) * C + c] = v;
+  }
+  if (i < C) packed[(size_t)2 * KK * C + i] = bias ? (float)bias[i] : 0.f;
+}
+
+// grads fp32 [ dwt (K*K x C) | db (C) ] -> dweight [C, K*K] and dbias [C] in dtype T
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_unpack_kernel(const float* __restrict__ g, T* __restrict__ dw,
+                                                            T* __restrict__ db, int C, int KK) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // i = c * KK + t
+  if (i < KK * C) {
+    const int c = i / KK, t = i % KK;
+    dw[i] = (T)g[(size_t)t * C + c];
+  }
+  if (db && i < C) db[i] = (T)g[(size_t)KK * C + i];
+}
+
 template <typename T, int V, int K, int TX>
 int fwd_launch(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C,
                int mode, hipStream_t s) {
