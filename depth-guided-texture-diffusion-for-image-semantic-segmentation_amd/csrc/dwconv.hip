@@ -156,23 +156,36 @@ __global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __re
     const int yy = yy0 + ky - P;
     if (yy < 0 || yy >= H) continue;                 // wave-uniform
     float g[TX][2];
-    const T* grow = du + (((size_t)b * H + yy0) * W) * C + c0;
-    const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+    const T* grow = du + (((size_t)b * H + yy0) * W + x0) * C + c0;
+    const T* row = x + (((size_t)b * H + yy) * W + x0 - P) * C + c0;
     float in[TX + K - 1][2];
+    if (x0 - P >= 0 && x0 + TX + P <= W) {          // interior strip (wave-uniform): straight-line loads, 32-bit offsets
 #pragma unroll
-    for (int t = 0; t < TX; ++t) {
-      if (x0 + t < W) {
-        PT v = *reinterpret_cast<const PT*>(grow + (size_t)(x0 + t) * C);
+      for (int t = 0; t < TX; ++t) {
+        PT v = *reinterpret_cast<const PT*>(grow + t * C);
         g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
-      } else { g[t][0] = 0.f; g[t][1] = 0.f; }
-    }
+      }
 #pragma unroll
-    for (int i = 0; i < TX + K - 1; ++i) {
-      const int xx = x0 + i - P;
-      if (xx >= 0 && xx < W) {
-        PT v = *reinterpret_cast<const PT*>(row + (size_t)xx * C);
+      for (int i = 0; i < TX + K - 1; ++i) {
+        PT v = *reinterpret_cast<const PT*>(row + i * C);
         in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
-      } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < TX; ++t) {
+        if (x0 + t < W) {
+          PT v = *reinterpret_cast<const PT*>(grow + t * C);
+          g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
+        } else { g[t][0] = 0.f; g[t][1] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) {
+        const int xx = x0 + i - P;
+        if (xx >= 0 && xx < W) {
+          PT v = *reinterpret_cast<const PT*>(row + i * C);
+          in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
+        } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+      }
     }
     if (ky == P) {
 #pragma unroll
@@ -234,17 +247,18 @@ int fwd_launch(const void* x, const float* wt, const float* bias, const void* au
 }
 
 // columns = B * ceil(W/TX) strip columns per channel block; split each column into `ysplit` row ranges until ~1024 workgroups exist
-static int bww_ysplit(int B, int H, int W, int C, int TX) {
+static int bww_ysplit(int B, int H, int W, int C, int TX, int K) {
   const int64_t cols = (int64_t)B * cdiv(W, TX) * (C / 128);
+  const int64_t target = K == 3 ? 4096 : 1024;   // workgroups are K waves: keep ~8-12k waves in flight
   int ys = 1;
-  while (ys < H && cols * ys < 1024 && (H / (ys * 2)) >= 4) ys *= 2;
+  while (ys < H && cols * ys < target && (H / (ys * 2)) >= 4) ys *= 2;
   return ys;
 }
 
 template <typename T, int K, int TX>
 int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, hipStream_t s) {
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
-  const int ncb = C / 128, ys = bww_ysplit(B, H, W, C, TX);
+  const int ncb = C / 128, ys = bww_ysplit(B, H, W, C, TX, K);
   const int gx = B * (int)cdiv(W, TX) * ys;
   hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(K * 64), 0, s, (const T*)x, (const T*)du, (float*)workspace,
                      has_bias, B, H, W, C, ys);
@@ -271,7 +285,7 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
 }
 
 extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K) {
-  const int ys = bww_ysplit(B, H, W, C, 8);
+  const int ys = bww_ysplit(B, H, W, C, 8, K);
   return (int64_t)B * cdiv(W, 8) * ys * (K * K + 1) * C * sizeof(float);
 }
 
