@@ -55,7 +55,7 @@ def _worker_body(rank, world, port, working, q):
         loss = ((out.float() - ys) ** 2).mean()
         loss.backward()
         red.finish()
-    grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+    grads = {n: p.grad.detach().numpy().copy() for n, p in net.named_parameters()}   # plain bytes: no fd passing between processes
     q.put((rank, grads))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,8 +81,9 @@ def test_grad_reducer_matches_large_batch(working):
     ((net(x) - y) ** 2).mean().backward()
     tol = dict(rtol=5e-2, atol=5e-3) if working else dict(rtol=1e-5, atol=1e-6)
     for n, p in net.named_parameters():
-        torch.testing.assert_close(got[0][n], got[1][n], rtol=0, atol=0)   # ranks agree bit-for-bit
-        torch.testing.assert_close(got[0][n], p.grad, **tol)
+        a, b = torch.from_numpy(got[0][n]), torch.from_numpy(got[1][n])
+        torch.testing.assert_close(a, b, rtol=0, atol=0)   # ranks agree bit-for-bit
+        torch.testing.assert_close(a, p.grad, **tol)
 
 
 def test_single_process_reducer_and_optimizer_groups():
