@@ -66,6 +66,12 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run shows where it is stuck
     t_start = time.perf_counter()
+    try:   # no-op when libdgtd.so / libdgtd_torch.so are newer than their sources (they travel with the repo snapshot)
+        import __graft_entry__ as _ge
+        if int(os.environ.get("LOCAL_RANK", 0)) == 0:
+            _ge.build()
+    except Exception as e:  # keep going with the libraries already in the tree; a missing library still fails loudly below
+        print(f"[bench] build() skipped: {e}", file=sys.stderr, flush=True)
     import dgtd
     rank, local, world = dgtd.dist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
