@@ -182,6 +182,7 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
 // ------------------------------------------------------------------------------------------------ Linear (library GEMMs + colsum bias grad)
 Tensor colsum(const Tensor& x2) {
   const int64_t rows = x2.size(0), C = x2.size(1);
+  if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat);   // narrower than a 16-byte chunk per lane
   Tensor out = at::empty({C}, x2.options().dtype(at::kFloat));
   Tensor ws = at::empty({dgtd_colsum_workspace((int)C)}, x2.options().dtype(at::kByte));
   check(dgtd_colsum(x2.data_ptr(), out.data_ptr<float>(), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");

@@ -27,6 +27,8 @@ def colsum(x2d: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of a [rows, C] matrix (bias gradients)."""
     L.check_cuda(x2d)
     rows, C = x2d.shape
+    if C % (16 // x2d.element_size()):   # narrower than one 16-byte chunk per lane (e.g. a 1-wide head): generic device reduction
+        return x2d.sum(0, dtype=torch.float32)
     out = torch.empty(C, dtype=torch.float32, device=x2d.device)
     ws = _workspace(L.load().dgtd_colsum_workspace(C), x2d.device)
     L.call("dgtd_colsum", L.ptr(x2d), L.ptr(out), L.ptr(ws), rows, C, L.dtype_code(x2d), L.stream_ptr(),
