@@ -133,3 +133,38 @@ def test_bf16_mode_close_to_oracle(dgtd):
     assert np.abs(logit - ref).mean() < 0.06
     band = np.abs(ref) < 0.1
     assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])
+
+
+@pytest.mark.parametrize("S,B", [(96, 1), (128, 2)])
+def test_whole_model_vs_oracle_other_sizes(dgtd, S, B):
+    """Sizes without a committed golden: run the oracle on the host and compare directly (fp32 mode, eval).
+    S=96 gives N_kv = 9 (ragged attention tiles), S=128 gives N_kv = 16."""
+    ref = cod_cpu.cod(S).eval()
+    filler.fill_module(ref)
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().eval()
+    x, d, l = filler.synthetic_batch(B, S, seed=S)
+    with torch.no_grad():
+        _, P1r, P2r = ref.hitnet(x, d)
+        want_loss = ref(None, x, l, d, mode="loss")["loss"].item()
+        _, P1, P2 = net.hitnet(x.cuda(), d.cuda())
+        got_loss = net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"].item()
+    ref_logit = (P1r[-1] + P2r).numpy()
+    logit = (P1[-1] + P2).cpu().numpy()
+    assert np.abs(logit - ref_logit).max() <= LOGIT_TOL
+    band = np.abs(ref_logit) < LOGIT_TOL
+    assert np.array_equal((logit > 0)[~band], (ref_logit > 0)[~band])
+    assert abs(got_loss - want_loss) <= LOGIT_TOL
+
+
+def test_batch_of_one_and_list_inputs(dgtd):
+    """mmengine's pseudo_collate hands cod.forward LISTS of per-sample tensors (cod.py:120-124); batch 1 also exercises the
+    per-sample DropPath plan and the BatchNorm batch statistics with a single sample."""
+    net = dgtd.nn.cod(compute_dtype=torch.bfloat16).cuda().train()
+    x, d, l = filler.synthetic_batch(1, 64, seed=3)
+    out = net(["a.png"], [x[0].cuda()], [l[0].cuda()], [d[0].cuda()], mode="loss")
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"])
+    g = net.hitnet.backbone.prompt_encoder.propagation_weight_regressor.reg.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
