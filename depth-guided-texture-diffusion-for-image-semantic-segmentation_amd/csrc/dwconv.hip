@@ -49,16 +49,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 #pragma unroll
       for (int t = 0; t < TX; ++t) acc[t][j] = bv;
     }
-    // Filter rows are software-pipelined: the loads of row ky+1 (input strip and its K weight vectors) are issued before the
-    // FMAs of row ky, so a wave always has one row of loads in flight behind its arithmetic (two named register sets).
-    auto load_row = [&](int ky, float (&in)[TX + K - 1][V], float (&wv)[K][V]) {
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {   // not unrolled: keeps ~1 row of taps live -> high occupancy hides the L2 latency
       const int yy = yy0 + ky - P;
-      const bool ok = (yy >= 0 && yy < H);
-      const T* row = x + (((size_t)b * H + (ok ? yy : yy0)) * W) * C + c0;
+      if (yy < 0 || yy >= H) continue;
+      const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+      float in[TX + K - 1][V];
 #pragma unroll
       for (int i = 0; i < TX + K - 1; ++i) {
         const int xx = x0 + i - P;
-        if (ok && xx >= 0 && xx < W) {
+        if (xx >= 0 && xx < W) {
           VT v = *reinterpret_cast<const VT*>(row + (size_t)xx * C);
 #pragma unroll
           for (int j = 0; j < V; ++j) in[i][j] = (float)v[j];
@@ -69,30 +69,18 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
+        float wv[V];
         const float* wp = wt + (size_t)(ky * K + kx) * C + c0;
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + j);
-          wv[kx][j] = w4[0]; wv[kx][j + 1] = w4[1]; wv[kx][j + 2] = w4[2]; wv[kx][j + 3] = w4[3];
+          wv[j] = w4[0]; wv[j + 1] = w4[1]; wv[j + 2] = w4[2]; wv[j + 3] = w4[3];
         }
-      }
-    };
-    auto fma_row = [&](const float (&in)[TX + K - 1][V], const float (&wv)[K][V]) {
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx)
 #pragma unroll
         for (int t = 0; t < TX; ++t)
 #pragma unroll
-          for (int j = 0; j < V; ++j) acc[t][j] += in[t + kx][j] * wv[kx][j];
-    };
-    float inA[TX + K - 1][V], inB[TX + K - 1][V], wA[K][V], wB[K][V];
-    load_row(0, inA, wA);
-#pragma unroll
-    for (int ky = 0; ky < K; ky += 2) {
-      if (ky + 1 < K) load_row(ky + 1, inB, wB);
-      fma_row(inA, wA);
-      if (ky + 2 < K) load_row(ky + 2, inA, wA);
-      if (ky + 1 < K) fma_row(inB, wB);
+          for (int j = 0; j < V; ++j) acc[t][j] += in[t + kx][j] * wv[j];
+      }
     }
     T* orow = y + (((size_t)b * H + yy0) * W) * C + c0;
 #pragma unroll
