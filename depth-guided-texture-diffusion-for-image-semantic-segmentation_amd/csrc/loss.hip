@@ -118,23 +118,25 @@ __global__ void loss_finish_kernel(const float* __restrict__ sums, const float* 
   loss[0] = tot;
 }
 
-// dlo[k][b][cy][cx] = gscale * mix[k]/B * sum_pixels bilinear_weight(pixel -> cell) * dL/dz(pixel)
+// dlo[k][b][cy][cx] = gout * mix[k]/B * sum_pixels bilinear_weight(pixel -> cell) * dL_k/dz(pixel), all five maps in one gather
 __global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ lo, const float* __restrict__ gt,
                                                       const float* __restrict__ weit, const float* __restrict__ sums,
                                                       const float* __restrict__ wsum, const float* __restrict__ mix,
                                                       const float* __restrict__ gout, float* __restrict__ dlo, int B, int S, int hs) {
-  const int cell = blockIdx.x, cy = cell / hs, cx = cell % hs, b = blockIdx.y, k = blockIdx.z, lane = threadIdx.x;
+  const int cell = blockIdx.x, cy = cell / hs, cx = cell % hs, b = blockIdx.y, lane = threadIdx.x;
   const float scale = (float)hs / (float)S;
-  const float* m = lo + ((size_t)k * B + b) * hs * hs;
-  const float* p3 = sums + ((size_t)k * B + b) * 3;
-  const float I = p3[1], U = p3[2], Nn = I + 1.f, Dn = U - I + 1.f, Wb = wsum[b];
-  const float coef = gout[0] * mix[k] / (float)B;
+  const float Wb = wsum[b];
+  float Nn[NMAP], Dn[NMAP], acc[NMAP];
+#pragma unroll
+  for (int k = 0; k < NMAP; ++k) {
+    const float* p3 = sums + ((size_t)k * B + b) * 3;
+    Nn[k] = p3[1] + 1.f; Dn[k] = p3[2] - p3[1] + 1.f; acc[k] = 0.f;
+  }
   // label pixels that can touch this cell: src in (c-1, c+1)
   const int lo_y = max(0, (int)floorf((cy - 0.5f) / scale - 0.5f) - 1), hi_y = min(S - 1, (int)ceilf((cy + 1.5f) / scale - 0.5f) + 1);
   const int lo_x = max(0, (int)floorf((cx - 0.5f) / scale - 0.5f) - 1), hi_x = min(S - 1, (int)ceilf((cx + 1.5f) / scale - 0.5f) + 1);
   const int ny = hi_y - lo_y + 1, nx = hi_x - lo_x + 1;
   const size_t plane = (size_t)b * S * S;
-  float acc = 0.f;
   for (int i = lane; i < ny * nx; i += 64) {
     const int y = lo_y + i / nx, x = lo_x + i % nx;
     int y0, y1, x0, x1; float ly, lx;
@@ -144,17 +146,24 @@ __global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ 
     const float wx = (x0 == cx ? 1.f - lx : 0.f) + (x1 == cx ? lx : 0.f);
     const float wc = wy * wx;
     if (wc != 0.f) {
-      const float z = (1.f - ly) * ((1.f - lx) * m[y0 * hs + x0] + lx * m[y0 * hs + x1]) + ly * ((1.f - lx) * m[y1 * hs + x0] + lx * m[y1 * hs + x1]);
       const float w = weit[plane + (size_t)y * S + x], t = gt[plane + (size_t)y * S + x];
-      const float e = expf(-fabsf(z));
-      const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-      const float ds = sg * (1.f - sg);
-      const float g = w * (sg - t) / Wb - w * ds * (t * Dn - Nn * (1.f - t)) / (Dn * Dn);
-      acc += wc * g;
+      const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+      for (int k = 0; k < NMAP; ++k) {
+        const float* m = lo + ((size_t)k * B + b) * hs * hs;
+        const float z = w00 * m[y0 * hs + x0] + w01 * m[y0 * hs + x1] + w10 * m[y1 * hs + x0] + w11 * m[y1 * hs + x1];
+        const float e = expf(-fabsf(z));
+        const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float ds = sg * (1.f - sg);
+        acc[k] += wc * (w * (sg - t) / Wb - w * ds * (t * Dn[k] - Nn[k] * (1.f - t)) / (Dn[k] * Dn[k]));
+      }
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) dlo[((size_t)k * B + b) * hs * hs + cell] = coef * acc;
+#pragma unroll
+  for (int k = 0; k < NMAP; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) dlo[((size_t)k * B + b) * hs * hs + cell] = gout[0] * mix[k] / (float)B * v;
+  }
 }
 
 }  // namespace
@@ -188,7 +197,7 @@ extern "C" int dgtd_seg_loss_bwd(const float* lo, const float* label, const floa
   const float* weit = (const float*)workspace;
   const float* sums = weit + (size_t)B * S * S;
   const float* wsum = sums + (size_t)NMAP * B * 3;
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(hs * hs, B, NMAP), dim3(64), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(hs * hs, B), dim3(64), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
   DGTD_CHECK_LAUNCH("loss_bwd");
   return 0;
 }

@@ -468,13 +468,21 @@ class PyramidVisionTransformerImpr(nn.Module):
         return self.forward_features(x, depth, x_hp)
 
 
-class pvt_v2_b2(PyramidVisionTransformerImpr):
-    """cod.py:1781-1787."""
-
+def _pvt_variant(name, depths, mlp_ratios, doc):
     def __init__(self, **kwargs):
-        super().__init__(patch_size=4, embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8], mlp_ratios=[8, 8, 4, 4],
-                         qkv_bias=True, depths=[3, 4, 6, 3], sr_ratios=[8, 4, 2, 1], drop_rate=0.0,
-                         drop_path_rate=kwargs.get("drop_path_rate", 0.1))
+        PyramidVisionTransformerImpr.__init__(self, patch_size=4, embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8],
+                                              mlp_ratios=mlp_ratios, qkv_bias=True, depths=depths, sr_ratios=[8, 4, 2, 1],
+                                              drop_rate=0.0, drop_path_rate=kwargs.get("drop_path_rate", 0.1))
+    return type(name, (PyramidVisionTransformerImpr,), {"__init__": __init__, "__doc__": doc})
+
+
+# cod.py:1773-1812.  Every variant with head_dim 64 (the attention kernel's specialisation); b0 (head_dim 32) is not on any path.
+pvt_v2_b1 = _pvt_variant("pvt_v2_b1", [2, 2, 2, 2], [8, 8, 4, 4], "cod.py:1773-1779")
+pvt_v2_b2 = _pvt_variant("pvt_v2_b2", [3, 4, 6, 3], [8, 8, 4, 4], "cod.py:1781-1787 — the backbone Hitnet hard-codes (cod.py:689)")
+pvt_v2_b3 = _pvt_variant("pvt_v2_b3", [3, 4, 18, 3], [8, 8, 4, 4], "cod.py:1789-1795")
+pvt_v2_b4 = _pvt_variant("pvt_v2_b4", [3, 8, 27, 3], [8, 8, 4, 4], "cod.py:1797-1803")
+pvt_v2_b5 = _pvt_variant("pvt_v2_b5", [3, 6, 40, 3], [4, 4, 4, 4], "cod.py:1806-1812")
+PVT_VARIANTS = {"pvt_v2_b1": pvt_v2_b1, "pvt_v2_b2": pvt_v2_b2, "pvt_v2_b3": pvt_v2_b3, "pvt_v2_b4": pvt_v2_b4, "pvt_v2_b5": pvt_v2_b5}
 
 
 # ------------------------------------------------------------------------------------------------ Hitnet decoder
@@ -558,10 +566,11 @@ class Hitnet(nn.Module):
     """cod.py:685-807."""
 
     def __init__(self, channel=32, n_feat=32, scale_unetfeats=32, kernel_size=3, reduction=4, bias=False, act=None,
-                 drop_path_rate=0.1):
+                 drop_path_rate=0.1, backbone: str = "pvt_v2_b2"):
         super().__init__()
         act = act if act is not None else nn.PReLU()  # ONE shared instance (default argument at cod.py:686)
-        self.backbone = pvt_v2_b2(drop_path_rate=drop_path_rate)
+        # the reference hard-codes pvt_v2_b2 (cod.py:689); b1/b3/b4/b5 fit the same 64/128/320/512 Translayers ("tier B", SURVEY §7)
+        self.backbone = PVT_VARIANTS[backbone](drop_path_rate=drop_path_rate)
         if drop_path_rate == 0.0:
             for m in self.backbone.modules():
                 if isinstance(m, DropPath):
@@ -652,9 +661,9 @@ class cod(nn.Module):
 
     def __init__(self, win_size=None, filter_ratio=None, using_depth=None, using_sam=None, finetune=None,
                  binary_thresh=None, pretrain_sam=None, head=None, img_size: int = 384,
-                 compute_dtype: torch.dtype = torch.float32, drop_path_rate: float = 0.1):
+                 compute_dtype: torch.dtype = torch.float32, drop_path_rate: float = 0.1, backbone: str = "pvt_v2_b2"):
         super().__init__()
-        self.hitnet = Hitnet(drop_path_rate=drop_path_rate)
+        self.hitnet = Hitnet(drop_path_rate=drop_path_rate, backbone=backbone)
         self.batch = 0
         self.compute_dtype = compute_dtype
         self._dp_plan = {"masks": None}

@@ -168,3 +168,33 @@ def test_batch_of_one_and_list_inputs(dgtd):
     assert torch.isfinite(out["loss"])
     g = net.hitnet.backbone.prompt_encoder.propagation_weight_regressor.reg.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+def test_config4_1024_inference_vs_oracle(dgtd):
+    """BASELINE.json configs[3]: 1024x1024 high-resolution inference (N = 65536 queries x N_kv = 1024 keys in stage 1:
+    the multi-chunk online-softmax path of the attention kernel inside the whole model).  Batch 1 keeps the CPU oracle at a few
+    seconds; predict mode (cod.py:152-153 + :219)."""
+    S = 1024
+    ref = cod_cpu.cod(S).eval()
+    filler.fill_module(ref)
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().eval()
+    x, d, l = filler.synthetic_batch(1, S, seed=7)
+    with torch.no_grad():
+        want, _ = ref(None, x, l, d, mode="predict")
+        got, _ = net(None, x.cuda(), l.cuda(), d.cuda(), mode="predict")
+    want, got = want.numpy(), got.cpu().numpy()
+    assert np.abs(got - want).max() <= LOGIT_TOL            # probabilities: the 1e-3 logit budget maps to <= 2.5e-4 here
+    band = np.abs(want - 0.5) < LOGIT_TOL
+    assert np.array_equal((got > 0.5)[~band], (want > 0.5)[~band])
+
+
+def test_tier_b_backbone_builds_and_trains(dgtd):
+    """Config 3's "tier B" backbone: pvt_v2_b3 swapped into Hitnet (cod.py:1789-1795)."""
+    net = dgtd.nn.cod(compute_dtype=torch.bfloat16, backbone="pvt_v2_b3").cuda().train()
+    assert len(net.hitnet.backbone.block3) == 18
+    x, d, l = filler.synthetic_batch(2, 64, seed=5)
+    loss = net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and net.hitnet.backbone.block3[17].attn.q.weight.grad is not None
