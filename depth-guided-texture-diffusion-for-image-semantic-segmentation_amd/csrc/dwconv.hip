@@ -10,6 +10,18 @@
 // bwd-data is the same kernel with the spatially flipped filter.  bwd-weight keeps a K*K x 2-channel accumulator per
 // lane, sums the four waves of a workgroup through LDS atomics and leaves with one fp32 global atomic per tap/channel.
 #include "common.h"
+#include <stdlib.h>
+
+// LDS-tiled variants (dwconv_tiled.hip), used whenever C % 128 == 0; DGTD_DWCONV_TILED=0 selects the direct kernels for A/B runs
+int dgtd_dwconv_tiled_fwd(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C, int K,
+                          int mode, dgtd_dtype dt, hipStream_t s);
+int dgtd_dwconv_tiled_bww(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, int K,
+                          dgtd_dtype dt, hipStream_t s);
+int dgtd_dwconv_tiled_bww_groups(int B, int H, int W, int C);
+static bool use_tiled() {
+  static const bool on = [] { const char* e = getenv("DGTD_DWCONV_TILED"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 namespace {
 
@@ -277,6 +289,8 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
   DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
+  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_fwd: bad dtype %d", (int)dt);
+  if (C % 128 == 0 && use_tiled()) return dgtd_dwconv_tiled_fwd(x, w_t, bias, aux, y, B, H, W, C, K, mode, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
                                      : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
@@ -286,7 +300,9 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
 
 extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K) {
   const int ys = bww_ysplit(B, H, W, C, 8, K);
-  return (int64_t)B * cdiv(W, 8) * ys * (K * K + 1) * C * sizeof(float);
+  const int64_t direct = (int64_t)B * cdiv(W, 8) * ys;
+  const int64_t tiled = C % 128 == 0 ? dgtd_dwconv_tiled_bww_groups(B, H, W, C) : 0;
+  return std::max(direct, tiled) * (K * K + 1) * C * sizeof(float);
 }
 
 extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W,
@@ -294,6 +310,9 @@ extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grad
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight: K=%d (only 3 and 7 are on the path)", K);
   hipStream_t st = (hipStream_t)s;
+  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_bwd_weight: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
+  if (use_tiled()) return dgtd_dwconv_tiled_bww(x, du, grads, has_bias, workspace, B, H, W, C, K, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
                                      : bww_launch<bf16_t, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
