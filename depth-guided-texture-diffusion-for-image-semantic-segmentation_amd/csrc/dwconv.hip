@@ -312,7 +312,9 @@ extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grad
   hipStream_t st = (hipStream_t)s;
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_bwd_weight: bad dtype %d", (int)dt);
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
-  if (use_tiled()) return dgtd_dwconv_tiled_bww(x, du, grads, has_bias, workspace, B, H, W, C, K, dt, st);
+  // measured: the K-wave direct kernel below beats the LDS-tiled weight gradient on every shape of the model (its accumulators
+  // never leave the wave); the tiled variant stays selectable for experiments
+  if (use_tiled() && getenv("DGTD_DWCONV_TILED_BWW")) return dgtd_dwconv_tiled_bww(x, du, grads, has_bias, workspace, B, H, W, C, K, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
                                      : bww_launch<bf16_t, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)

@@ -23,21 +23,30 @@ template <typename T> struct Pair2;
 template <> struct Pair2<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Pair2<bf16_t> { typedef bf16_t type __attribute__((ext_vector_type(2))); };
 
-// stage rows [y0 - P, y0 + TY + P) x cols [x0 - P, x0 + TXW + P) x channels [cb*128, +128) of image b into LDS, zero padded
+// stage rows [y0 - P, y0 + TY + P) x cols [x0 - P, x0 + TXW + P) x channels [cb*128, +128) of image b into LDS, zero padded.
+// All of a thread's 16-byte loads are issued before the first LDS store (fully unrolled, registers), so the tile arrives with
+// one round trip of latency instead of one per chunk.
 template <typename T, int K>
 __device__ __forceinline__ void stage_tile(T* __restrict__ tile, const T* __restrict__ x, int b, int y0, int x0, int cb, int H, int W,
-                                           int C, int tid, int nthr) {
+                                           int C, int tid) {
   typedef typename Vec16<T>::type VT;
   constexpr int V = Vec16<T>::N, P = K / 2, RW = TXW + K - 1, RH = TY + K - 1, CPP = 128 / V;   // 16-B chunks per position
-  for (int i = tid; i < RH * RW * CPP; i += nthr) {
+  constexpr int TOTAL = RH * RW * CPP, NCH = (TOTAL + 255) / 256;
+  VT v[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int i = tid + k * 256;
     const int ch = i % CPP, pos = i / CPP, xx = pos % RW, yy = pos / RW;
     const int gy = y0 + yy - P, gx = x0 + xx - P;
-    VT v;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const VT*>(x + (((size_t)b * H + gy) * W + gx) * C + cb * 128 + ch * V);
+    if (i < TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W) v[k] = *reinterpret_cast<const VT*>(x + (((size_t)b * H + gy) * W + gx) * C + cb * 128 + ch * V);
     else
 #pragma unroll
-      for (int j = 0; j < V; ++j) v[j] = (T)0.f;
-    *reinterpret_cast<VT*>(tile + (size_t)pos * 128 + ch * V) = v;
+      for (int j = 0; j < V; ++j) v[k][j] = (T)0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int i = tid + k * 256;
+    if (i < TOTAL) *reinterpret_cast<VT*>(tile + (size_t)i * V) = v[k];   // pos * 128 + ch * V == i * V
   }
 }
 
@@ -60,12 +69,12 @@ __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restri
   const int tx = t % txn;
   const int b = t / txn;
   const int y0 = ty * TY, x0 = tx * TXW, c0 = cb * 128 + lane * 2;
-  // all K*K taps of this lane's two channels, and the bias, stay in registers
+  stage_tile<T, K>(tile, x, b, y0, x0, cb, H, W, C, tid);
+  // all K*K taps of this lane's two channels, and the bias, stay in registers (loaded behind the tile: the staging registers are dead)
   float w[K * K][2];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) { w[i][0] = wt[(size_t)i * C + c0]; w[i][1] = wt[(size_t)i * C + c0 + 1]; }
   const float b0 = bias ? bias[c0] : 0.f, b1 = bias ? bias[c0 + 1] : 0.f;
-  stage_tile<T, K>(tile, x, b, y0, x0, cb, H, W, C, tid, 256);
   __syncthreads();
   const int oy = y0 + wave;                       // this wave's output row
   if (oy >= H) return;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_bww_kernel(const T* __restri
     const int b = r / txn;
     const int y0 = ty * TY, x0 = tx * TXW;
     __syncthreads();                               // previous tile fully consumed
-    stage_tile<T, K>(tile, x, b, y0, x0, cb, H, W, C, tid, 256);
+    stage_tile<T, K>(tile, x, b, y0, x0, cb, H, W, C, tid);
     for (int i = tid; i < TY * TXW * CPP; i += 256) {
       const int ch = i % CPP, pos = i / CPP, xx = pos % TXW, yy = pos / TXW;
       const int gy = y0 + yy, gx = x0 + xx;
