@@ -1,0 +1,229 @@
+// hitnet_glue.hip — elementwise / small-reduction glue of the Hitnet CAB decoder (twig/model/cod.py:415-451) on channels_last
+// feature maps viewed as token matrices [B, HW, C]:
+//   prelu      : y = x > 0 ? x : a*x with ONE shared slope (the default-argument nn.PReLU() of cod.py:686, used by all 8 CABs);
+//                backward dx = g*(x>0 ? 1 : a), da = sum_{x<=0} g*x   (torch's generic PReLU backward materialises a full-size
+//                per-element weight gradient and reduces it: 1.8 ms per step)
+//   ca_gate    : out = res * sigmoid(W2 relu(W1 mean_hw(res))) + x     (CALayer cod.py:428-431 + the residual of CAB cod.py:449-451)
+//                three launches forward (pooled sums, gate, apply), three backward; C <= 128, C/r <= 32
+// HBM-bound: prelu 2e*n (fwd) / 3e*n (bwd); ca_gate fwd 4e*n (res twice, x, out), bwd 4e*n.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a, T* __restrict__ y, int64_t n) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const float slope = a[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / V; i += (int64_t)gridDim.x * 256) {
+    VT v = *reinterpret_cast<const VT*>(x + i * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const float f = (float)v[j]; o[j] = (T)(f > 0.f ? f : slope * f); }
+    *reinterpret_cast<VT*>(y + i * V) = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ a,
+                                                        T* __restrict__ dx, float* __restrict__ da, int64_t n) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[4];
+  const float slope = a[0];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / V; i += (int64_t)gridDim.x * 256) {
+    VT xv = *reinterpret_cast<const VT*>(x + i * V), gv = *reinterpret_cast<const VT*>(g + i * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float f = (float)xv[j], gg = (float)gv[j];
+      o[j] = (T)(f > 0.f ? gg : slope * gg);
+      acc += f > 0.f ? 0.f : gg * f;
+    }
+    *reinterpret_cast<VT*>(dx + i * V) = o;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(da, red[0] + red[1] + red[2] + red[3]);
+}
+
+// pooled[b][c] += sum over a slice of the HW rows of a[b][hw][c] (* optional second factor bfac)   (atomics: B*C addresses, few adders)
+template <typename T, bool PRODUCT>
+__global__ __launch_bounds__(256) void pooled_sum_kernel(const T* __restrict__ a, const T* __restrict__ bfac, float* __restrict__ pooled,
+                                                         int HW, int C) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int cpr = 256 / C > 0 ? 256 / C : 1;          // rows handled per pass (C <= 128 -> at least 2)
+  const int c = tid % C, rl = tid / C;
+  float acc = 0.f;
+  if (rl < cpr) {
+    for (int r = blockIdx.x * cpr + rl; r < HW; r += gridDim.x * cpr) {
+      const size_t o = ((size_t)b * HW + r) * C + c;
+      acc += PRODUCT ? (float)a[o] * (float)bfac[o] : (float)a[o];
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int k = 0; k < cpr; ++k) s += red[k * C + tid];
+    atomicAdd(&pooled[b * C + tid], s);
+  }
+}
+
+// gate[b][c] = sigmoid(W2 relu(W1 (pooled[b]/HW)));  hidden[b][j] kept for the backward.  One workgroup per sample.
+__global__ __launch_bounds__(128) void ca_gate_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, float* __restrict__ gate, float* __restrict__ hidden,
+                                                          int HW, int C, int R) {
+  __shared__ float m[128], hdn[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < C) m[tid] = pooled[b * C + tid] / (float)HW;
+  __syncthreads();
+  if (tid < R) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += w1[tid * C + c] * m[c];
+    s = fmaxf(s, 0.f);
+    hdn[tid] = s;
+    hidden[b * R + tid] = s;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int j = 0; j < R; ++j) s += w2[tid * R + j] * hdn[j];
+    gate[b * C + tid] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// out = res * gate[b][c] + x
+template <typename T>
+__global__ __launch_bounds__(256) void ca_apply_kernel(const T* __restrict__ res, const T* __restrict__ x, const float* __restrict__ gate,
+                                                       T* __restrict__ out, int64_t rows, int HW, int C) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * CV; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int b = (int)((i / CV) / HW);
+    VT r = *reinterpret_cast<const VT*>(res + i * V), xv = *reinterpret_cast<const VT*>(x + i * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = (T)((float)r[j] * gate[b * C + cv * V + j] + (float)xv[j]);
+    *reinterpret_cast<VT*>(out + i * V) = o;
+  }
+}
+
+// backward of the tiny MLP per sample: dgate_sum[b][c] = sum_hw g*res (given) -> dmean[b][c]; dW1, dW2 accumulated over the batch
+__global__ __launch_bounds__(128) void ca_gate_mlp_bwd_kernel(const float* __restrict__ dgsum, const float* __restrict__ gate,
+                                                              const float* __restrict__ hidden, const float* __restrict__ pooled,
+                                                              const float* __restrict__ w1, const float* __restrict__ w2,
+                                                              float* __restrict__ dmean, float* __restrict__ dw1, float* __restrict__ dw2,
+                                                              int HW, int C, int R) {
+  __shared__ float dz[128], dh[32], m[128], hdn[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < C) {
+    const float gt = gate[b * C + tid];
+    dz[tid] = dgsum[b * C + tid] * gt * (1.f - gt);      // through the sigmoid
+    m[tid] = pooled[b * C + tid] / (float)HW;
+  }
+  if (tid < R) hdn[tid] = hidden[b * R + tid];
+  __syncthreads();
+  if (tid < R) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += w2[c * R + tid] * dz[c];
+    dh[tid] = hdn[tid] > 0.f ? s : 0.f;                  // through the ReLU
+  }
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int j = 0; j < R; ++j) s += w1[j * C + tid] * dh[j];
+    dmean[b * C + tid] = s / (float)HW;                  // d loss / d res[b][hw][c] through the mean
+    for (int j = 0; j < R; ++j) {
+      atomicAdd(&dw2[tid * R + j], dz[tid] * hdn[j]);
+      atomicAdd(&dw1[j * C + tid], dh[j] * m[tid]);
+    }
+  }
+}
+
+// dres = g * gate[b][c] + dmean[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const T* __restrict__ g, const float* __restrict__ gate, const float* __restrict__ dmean,
+                                                           T* __restrict__ dres, int64_t rows, int HW, int C) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * CV; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int b = (int)((i / CV) / HW);
+    VT gv = *reinterpret_cast<const VT*>(g + i * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = (T)((float)gv[j] * gate[b * C + cv * V + j] + dmean[b * C + cv * V + j]);
+    *reinterpret_cast<VT*>(dres + i * V) = o;
+  }
+}
+
+inline int ew_grid(int64_t items) { return (int)std::min<int64_t>(cdiv(items, 256), 2048); }
+
+}  // namespace
+
+extern "C" int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n, dgtd_dtype dt, dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_fwd: n=%lld must be a positive multiple of %d", (long long)n, V);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_fwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, a, (bf16_t*)y, n);
+  else if (dt == DGTD_F32) hipLaunchKernelGGL(prelu_fwd_kernel<float>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const float*)x, a, (float*)y, n);
+  else DGTD_FAIL(2, "prelu_fwd: bad dtype %d", (int)dt);
+  DGTD_CHECK_LAUNCH("prelu_fwd");
+  return 0;
+}
+
+extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float* da, int64_t n, dgtd_dtype dt, dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_bwd: n=%lld must be a positive multiple of %d", (long long)n, V);
+  const int grid = std::min(ew_grid(n / V), 512);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)g, a, (bf16_t*)dx, da, n);
+  else if (dt == DGTD_F32) hipLaunchKernelGGL(prelu_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)g, a, (float*)dx, da, n);
+  else DGTD_FAIL(2, "prelu_bwd: bad dtype %d", (int)dt);
+  DGTD_CHECK_LAUNCH("prelu_bwd");
+  return 0;
+}
+
+// stats fp32 [B*C (pooled sums) | B*C (gate) | B*R (hidden)]: pooled must be ZEROED by the caller
+extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats, int B, int HW,
+                                int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_fwd: unsupported sizes C=%d R=%d", C, R);
+  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
+  hipStream_t st = (hipStream_t)s;
+  float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
+  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, pooled, HW, C);
+  else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, pooled, HW, C);
+  DGTD_CHECK_LAUNCH("ca_pooled_sum");
+  hipLaunchKernelGGL(ca_gate_mlp_kernel, dim3(B), dim3(128), 0, st, (const float*)pooled, w1, w2, gate, hidden, HW, C, R);
+  DGTD_CHECK_LAUNCH("ca_gate_mlp");
+  const int64_t rows = (int64_t)B * HW;
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)x, (const float*)gate, (bf16_t*)out, rows, HW, C);
+  else hipLaunchKernelGGL(ca_apply_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)res, (const float*)x, (const float*)gate, (float*)out, rows, HW, C);
+  DGTD_CHECK_LAUNCH("ca_apply");
+  return 0;
+}
+
+// scratch fp32 [B*C (dgate sums, ZEROED by the caller) | B*C (dmean)]; dw1 [R,C], dw2 [C,R] ZEROED by the caller; d(out)/dx is the identity
+extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                                float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_bwd: unsupported sizes C=%d R=%d", C, R);
+  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
+  hipStream_t st = (hipStream_t)s;
+  const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
+  float *dgsum = scratch, *dmean = scratch + (size_t)B * C;
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
+  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, dgsum, HW, C);
+  else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, dgsum, HW, C);
+  DGTD_CHECK_LAUNCH("ca_dgate_sum");
+  hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)dgsum, gate, hidden, pooled, w1, w2, dmean, dw1, dw2, HW, C, R);
+  DGTD_CHECK_LAUNCH("ca_gate_mlp_bwd");
+  const int64_t rows = (int64_t)B * HW;
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C);
+  else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C);
+  DGTD_CHECK_LAUNCH("ca_apply_bwd");
+  return 0;
+}

@@ -1,0 +1,100 @@
+"""Hitnet CAB decoder glue (twig/model/cod.py:415-451) over the C ABI: shared-slope PReLU and the fused
+channel-attention gate + residual.  Feature maps are logical [B,C,H,W] tensors in channels_last memory (what the MIOpen
+NHWC convolutions around them produce), i.e. [B,HW,C] token matrices for the kernels."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+
+def _dense(x: torch.Tensor) -> torch.Tensor:
+    if x.is_contiguous() or (x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return x
+    return x.contiguous()
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise L.DgtdError("dgtd ops run only on the MI355X HIP device (tensor is on %s)" % t.device)
+
+
+class _PReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        _require_cuda(x)
+        x = _dense(x)
+        a32 = a.detach().float().contiguous()
+        y = torch.empty_like(x)
+        L.call("dgtd_prelu_fwd", L.ptr(x), L.ptr(a32), L.ptr(y), x.numel(), L.dtype_code(x), L.stream_ptr(),
+               algo=("hbm", 2 * x.element_size() * x.numel()), key=f"dgtd_prelu_fwd[n={x.numel()}]")
+        ctx.save_for_backward(x, a32)
+        ctx.adtype = a.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, a32 = ctx.saved_tensors
+        if g.dtype != x.dtype or g.stride() != x.stride():
+            g = torch.empty_like(x).copy_(g)
+        dx = torch.empty_like(x)
+        da = torch.zeros(1, dtype=torch.float32, device=x.device)
+        L.call("dgtd_prelu_bwd", L.ptr(x), L.ptr(g), L.ptr(a32), L.ptr(dx), L.ptr(da), x.numel(), L.dtype_code(x),
+               L.stream_ptr(), algo=("hbm", 3 * x.element_size() * x.numel()), key=f"dgtd_prelu_bwd[n={x.numel()}]")
+        return dx, da.to(ctx.adtype)
+
+
+def prelu(x: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """nn.PReLU() with a single shared slope (cod.py:686; applied inside every CAB, cod.py:444-446)."""
+    if a.numel() != 1:
+        raise L.DgtdError("dgtd prelu implements the single-slope nn.PReLU() the reference constructs (cod.py:686)")
+    return _PReLUFn.apply(x, a)
+
+
+class _CAGateFn(Function):
+    @staticmethod
+    def forward(ctx, res, x, w1, w2):
+        _require_cuda(res, x)
+        res, x = _nhwc(res), _nhwc(x if x.dtype == res.dtype else x.to(res.dtype))
+        B, C, H, W = res.shape
+        R = w1.shape[0]
+        w1f = w1.detach().reshape(R, C).float().contiguous()
+        w2f = w2.detach().reshape(C, R).float().contiguous()
+        stats = torch.zeros(2 * B * C + B * R, dtype=torch.float32, device=res.device)
+        out = torch.empty_like(res)
+        L.call("dgtd_ca_gate_fwd", L.ptr(res), L.ptr(x), L.ptr(w1f), L.ptr(w2f), L.ptr(out), L.ptr(stats), B, H * W, C, R,
+               L.dtype_code(res), L.stream_ptr(), algo=("hbm", 4 * res.element_size() * res.numel()),
+               key=f"dgtd_ca_gate_fwd[B={B},HW={H * W},C={C}]")
+        ctx.save_for_backward(res, w1f, w2f, stats)
+        ctx.meta = (w1.shape, w1.dtype, w2.shape, w2.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        res, w1f, w2f, stats = ctx.saved_tensors
+        w1shape, w1dtype, w2shape, w2dtype = ctx.meta
+        B, C, H, W = res.shape
+        R = w1f.shape[0]
+        g = _nhwc(g if g.dtype == res.dtype else g.to(res.dtype))
+        dres = torch.empty_like(res)
+        small = torch.zeros(2 * R * C + 2 * B * C, dtype=torch.float32, device=res.device)
+        dw1, dw2, scratch = small[:R * C], small[R * C:2 * R * C], small[2 * R * C:]
+        L.call("dgtd_ca_gate_bwd", L.ptr(g), L.ptr(res), L.ptr(w1f), L.ptr(w2f), L.ptr(stats), L.ptr(dres), dw1.data_ptr(),
+               dw2.data_ptr(), scratch.data_ptr(), B, H * W, C, R, L.dtype_code(res), L.stream_ptr(),
+               algo=("hbm", 4 * res.element_size() * res.numel()), key=f"dgtd_ca_gate_bwd[B={B},HW={H * W},C={C}]")
+        return dres, g, dw1.view(w1shape).to(w1dtype), dw2.view(w2shape).to(w2dtype)
+
+
+def ca_gate(res: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """res * sigmoid(conv1x1_w2(relu(conv1x1_w1(avgpool(res))))) + x — CALayer (cod.py:428-431) and the CAB residual (cod.py:451).
+    w1 [C/r, C, 1, 1], w2 [C, C/r, 1, 1] are the bias-free conv_du weights (cod.py:421-425)."""
+    return _CAGateFn.apply(res, x, w1, w2)

@@ -126,6 +126,22 @@ int64_t dgtd_diffuse_tail_bwd_workspace(int B);
 int dgtd_diffuse_tail_bwd(const float* gout, const float* x4, const float* cw, float* g4, float* d_cw,
                           float* d_cb, void* workspace, int B, int S, dgtd_stream s);
 
+/* ---- Hitnet CAB decoder glue on channels_last maps viewed as [B, HW, C] ------------------------------
+ * PReLU with ONE shared slope a[1] (the default-argument nn.PReLU() of twig/model/cod.py:686, applied at cod.py:444-446):
+ * y = x > 0 ? x : a*x over n elements (any dense layout).                                                             */
+int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n, dgtd_dtype dt, dgtd_stream s);
+/* dx = g * (x > 0 ? 1 : a) overwritten; da[1] += sum_{x<=0} g*x, ZEROED by the caller.                                   */
+int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float* da, int64_t n,
+                   dgtd_dtype dt, dgtd_stream s);
+/* out = res * sigmoid(W2 relu(W1 mean_hw(res))) + x : CALayer.forward (cod.py:428-431) plus the residual of CAB.forward
+ * (cod.py:449-451).  res, x, out [B,HW,C]; w1 fp32 [R,C], w2 fp32 [C,R] (the bias-free 1x1 convs of cod.py:421-425);
+ * C <= 128, R <= 32.  stats fp32 [2*B*C + B*R] = { pooled sums (ZEROED by the caller) | gate | hidden }, kept for the backward. */
+int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats,
+                     int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
+/* dres [B,HW,C] overwritten (d out / d x is the identity); dw1 [R,C], dw2 [C,R] and scratch fp32 [2*B*C] ZEROED by the caller. */
+int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                     float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,3 +208,53 @@ def test_seg_loss_vs_oracle(dgtd, S, hs, B):
     assert abs(got.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
     for a, b, w in zip(gg, gw, mix):
         torch.testing.assert_close(a.cpu() / 1.5, b, atol=2e-7, rtol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------- Hitnet CAB glue
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16), (3, 96, 20, 12), (2, 64, 128, 128)], ids=str)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_prelu_shared_slope(dgtd, shape, dtype, channels_last):
+    x = _rand(*shape, seed=5, dtype=dtype)
+    g = _rand(*shape, seed=6, dtype=dtype)
+    if channels_last:
+        x, g = x.contiguous(memory_format=torch.channels_last), g.contiguous(memory_format=torch.channels_last)
+    a = torch.full((1,), 0.25, device="cuda").requires_grad_()
+    xr = x.float().requires_grad_()
+    ref = F.prelu(xr, a)
+    gx, ga = torch.autograd.grad(ref, (xr, a), g.float())
+    xs = x.clone().requires_grad_()
+    y = dgtd.ops.prelu(xs, a)
+    hx, ha = torch.autograd.grad(y, (xs, a), g)
+    assert y.dtype == dtype and y.stride() == x.stride()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
+    torch.testing.assert_close(ha, ga, atol=1e-3 * math.sqrt(x.numel()) * (1 if dtype == torch.float32 else 30), rtol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (3, 64, 12, 20), (2, 96, 64, 64), (1, 64, 128, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
+    """CALayer (cod.py:415-431) + the CAB residual (cod.py:451) against the plain torch composition in fp32."""
+    R = C // 4
+    res = _rand(B, C, H, W, seed=1, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    x = _rand(B, C, H, W, seed=2, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    g = _rand(B, C, H, W, seed=3, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    w1 = (_rand(R, C, 1, 1, seed=4) / math.sqrt(C)).requires_grad_()
+    w2 = (_rand(C, R, 1, 1, seed=5) / math.sqrt(R)).requires_grad_()
+    rr, xr = res.float().requires_grad_(), x.float().requires_grad_()
+    gate = torch.sigmoid(F.conv2d(F.relu(F.conv2d(rr.mean((2, 3), keepdim=True), w1)), w2))
+    ref = rr * gate + xr
+    gres, gxx, gw1, gw2 = torch.autograd.grad(ref, (rr, xr, w1, w2), g.float())
+    rs, xs = res.clone().requires_grad_(), x.clone().requires_grad_()
+    out = dgtd.ops.ca_gate(rs, xs, w1, w2)
+    hres, hx, hw1, hw2 = torch.autograd.grad(out, (rs, xs, w1, w2), g)
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hres.float(), gres, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gxx, atol=tol, rtol=tol)
+    wtol = 1e-4 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(hw1, gw1, atol=wtol * gw1.abs().max().item() + 1e-6, rtol=wtol)
+    torch.testing.assert_close(hw2, gw2, atol=wtol * gw2.abs().max().item() + 1e-6, rtol=wtol)
