@@ -38,7 +38,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size: int):
+def cpu_baseline(size: int, log=lambda m: None):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
     from oracle import cod_cpu
     try:
@@ -53,12 +53,16 @@ def cpu_baseline(size: int):
     x = torch.randn(B, 3, size, size, generator=g)
     d = torch.rand(B, 1, size, size, generator=g)
     l = (torch.rand(B, 1, size, size, generator=g) > 0.5).float()
-    t0 = time.perf_counter()
-    loss = net(None, x, l, d, mode="loss")["loss"]
-    loss.backward()
+    steps, t0 = 0, time.perf_counter()
+    while steps < 3 or time.perf_counter() - t0 < 12.0:      # ~12-20 s of CPU work
+        net.zero_grad(set_to_none=True)
+        loss = net(None, x, l, d, mode="loss")["loss"]
+        loss.backward()
+        steps += 1
+        log(f"cpu oracle step {steps}: {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 step fwd+loss+bwd of oracle/cod_cpu.py, {size}x{size}, batch {B}, fp32, {cores} torch threads, {dt:.1f} s"}
+    return {"value": steps * B / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps fwd+loss+bwd of oracle/cod_cpu.py, {size}x{size}, batch {B}, fp32, {cores} torch threads, {dt:.1f} s"}
 
 
 def main():
@@ -134,9 +138,25 @@ def main():
     # ---- instrumented pass: per-kernel HIP-event timing (not part of `value`)
     roofline, kernels = None, []
     if rank == 0 and args.profile_steps > 0:
+        # The step is host-bound, so an event pair around a launch would mostly time the host's enqueue gap.  Each
+        # instrumented step is therefore queued BEHIND a ballast of large GEMMs (about 2.5 step-times of device work): the
+        # host runs ahead, the launches and their event markers execute back to back, and the pairs measure device time.
+        ball = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        ball_out = torch.empty_like(ball)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(ball, ball, out=ball_out)
+        e0.record()
+        for _ in range(4):
+            torch.mm(ball, ball, out=ball_out)
+        e1.record()
+        torch.cuda.synchronize()
+        n_ball = int(2.5 * (1e3 * dt / args.steps) / max(e0.elapsed_time(e1) / 4, 0.1)) + 1
         dgtd._lib.PROFILER = dgtd._lib.Profiler()
         for i in range(args.profile_steps):
+            for _ in range(n_ball):
+                torch.mm(ball, ball, out=ball_out)
             step(i)
+        del ball, ball_out
         summ = dgtd._lib.PROFILER.summary()
         log("instrumented pass done")
         dgtd._lib.PROFILER = None
@@ -176,7 +196,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(args.size)
+            out["cpu_baseline"] = cpu_baseline(args.size, log)
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
 }
 
 // ws [nblocks][C] -> out[C]; one workgroup per 64 columns, 4 waves over the rows, fixed summation order
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks, int C) {
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, void* __restrict__ out, int out_bf16, int nblocks, int C) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   }
   part[wave][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && col < C) out[col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (wave == 0 && col < C) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (out_bf16) ((bf16_t*)out)[col] = (bf16_t)v;
+    else ((float*)out)[col] = v;
+  }
 }
 
 template <typename T>
@@ -123,8 +127,8 @@ int check_c(int C, const char* who) {
 }
 
 template <typename T, int MODE>
-int colsum_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* out, void* ws, int64_t rows,
-                  int C, int64_t rps, hipStream_t st, const char* who) {
+int colsum_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, void* out, void* ws, int64_t rows,
+                  int C, int64_t rps, hipStream_t st, const char* who, int out_bf16 = 0) {
   if (int rc = check_c<T>(C, who)) return rc;
   constexpr int V = Vec16<T>::N;
   const int CV = C / V, ncb = (int)cdiv(CV, 256);
@@ -134,7 +138,7 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
   hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
   if (MODE != 2) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, out, gx, C);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, out, out_bf16, gx, C);
     DGTD_CHECK_LAUNCH(who);
   }
   return 0;
@@ -169,9 +173,11 @@ extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float
   DGTD_FAIL(2, "scale_residual_bwd: bad dtype %d", (int)dt);
 }
 
-extern "C" int dgtd_colsum(const void* x, float* out, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
+extern "C" int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
   DGTD_REQUIRE(rows > 0 && C > 0, "colsum: bad sizes");
-  if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum");
-  if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum");
+  DGTD_REQUIRE(out_dt == DGTD_F32 || out_dt == DGTD_BF16, "colsum: bad output dtype %d", (int)out_dt);
+  const int ob = out_dt == DGTD_BF16;
+  if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
+  if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
   DGTD_FAIL(2, "colsum: bad dtype %d", (int)dt);
 }

@@ -180,12 +180,12 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
 };
 
 // ------------------------------------------------------------------------------------------------ Linear (library GEMMs + colsum bias grad)
-Tensor colsum(const Tensor& x2) {
+Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
   const int64_t rows = x2.size(0), C = x2.size(1);
-  if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat);   // narrower than a 16-byte chunk per lane
-  Tensor out = at::empty({C}, x2.options().dtype(at::kFloat));
+  if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat).to(out_dt);   // narrower than a 16-byte chunk per lane
+  Tensor out = at::empty({C}, x2.options().dtype(out_dt));
   Tensor ws = at::empty({dgtd_colsum_workspace((int)C)}, x2.options().dtype(at::kByte));
-  check(dgtd_colsum(x2.data_ptr(), out.data_ptr<float>(), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
+  check(dgtd_colsum(x2.data_ptr(), out.data_ptr(), code(out), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
   return out;
 }
 
@@ -229,7 +229,7 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     Tensor dw;
     if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
       Tensor part = at::bmm(dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
-      dw = at::sum(part, {0}, false, at::kFloat).to(dy2.scalar_type());
+      dw = at::sum(part, {0});   // bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
     } else {
       dw = at::mm(dy2.t(), x2);
     }
@@ -237,7 +237,7 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
     Tensor db;
     const int64_t bk = ctx->saved_data["b_kind"].toInt();
-    if (bk) { db = colsum(dy2); if (bk == 2) db = db.to(at::kBFloat16); }
+    if (bk) db = colsum(dy2, bk == 2 ? at::kBFloat16 : at::kFloat);
     return {dx, dw, db, undefined()};
   }
 };

@@ -75,7 +75,7 @@ class GradReducer:
         if self.working_dtype is not None:
             from ..nn.modules import Conv2d, Linear
             for m in module.modules():
-                if isinstance(m, (Linear, Conv2d)):
+                if isinstance(m, (Linear, Conv2d)) and not getattr(m, "keep_master", False):
                     castable[id(m.weight)] = (m, "_w")
                     if m.bias is not None:
                         castable[id(m.bias)] = (m, "_b")
@@ -116,20 +116,32 @@ class GradReducer:
         flat = torch.zeros(n_work + n_rest, dtype=torch.float32, device=dev)          # fp32 gradients
         mflat = torch.empty(n_work, dtype=torch.float32, device=dev) if n_work else None  # fp32 masters (castable part)
         wflat = torch.empty(n_work, dtype=self.working_dtype, device=dev) if n_work else None
-        masters, leaves, gviews = [], [], []
+        masters, leaves, gviews, nhwc = [], [], [], []
         off = 0
         with torch.no_grad():
             for _, p in work + rest:
                 n = p.numel()
-                gv = flat[off:off + n].view_as(p)
+                # Dense KxK convolution kernels live in O,H,W,I storage order (channels_last strides, logical shape unchanged):
+                # the NHWC convolutions then take the working copy as it is instead of re-laying it out on every call, and the
+                # weight gradient they return lands in the bucket without a layout copy.  k == stride convs are consumed as
+                # GEMM matrices through weight.flatten(1) and keep the O,I,H,W order.
+                cl = False
+                if id(p) in castable and p.ndim == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1:
+                    m = castable[id(p)][0]
+                    cl = tuple(m.stride) != tuple(m.kernel_size)
+                nhwc.append(cl)
+                view = (lambda t: t.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)) if cl \
+                    else (lambda t: t.view_as(p))
+                gv = view(flat[off:off + n])
                 p.grad = gv                      # master .grad = view of the flat fp32 bucket (what the optimizer reads)
                 masters.append(p)
                 gviews.append(gv)
                 if id(p) in castable:
                     m, attr = castable[id(p)]
-                    mflat[off:off + n].copy_(p.data.reshape(-1))
-                    p.data = mflat[off:off + n].view_as(p)
-                    leaf = wflat[off:off + n].view_as(p)
+                    mv = view(mflat[off:off + n])
+                    mv.copy_(p.data)
+                    p.data = mv
+                    leaf = view(wflat[off:off + n])
                     leaf.requires_grad_(True)    # a leaf: its base buffer does not require grad
                     object.__setattr__(m, attr, leaf)
                     p.requires_grad_(False)      # the master no longer takes part in autograd
@@ -138,7 +150,7 @@ class GradReducer:
                     leaves.append(p)
                 off += n
         self.buckets.append({"flat": flat, "mflat": mflat, "wflat": wflat, "n_work": n_work, "k_work": len(work),
-                             "masters": masters, "leaves": leaves, "gviews": gviews,
+                             "masters": masters, "leaves": leaves, "gviews": gviews, "nhwc": nhwc,
                              "pending": len(items), "n": len(items), "done": False})
 
     # ------------------------------------------------------------------ per step
@@ -170,7 +182,10 @@ class GradReducer:
         """Leaf gradients -> flat fp32 bucket: one batched concat per dtype segment (+ one cast for the
         low-precision segment) instead of a copy kernel per parameter; then restore the master .grad views."""
         flat, k, nw = bucket["flat"], bucket["k_work"], bucket["n_work"]
-        leaves, gviews = bucket["leaves"], bucket["gviews"]
+        leaves, gviews, nhwc = bucket["leaves"], bucket["gviews"], bucket["nhwc"]
+
+        def flat1d(g, cl):   # the gradient in the bucket's storage order (a view when its strides already match)
+            return g.permute(0, 2, 3, 1).reshape(-1) if cl else g.reshape(-1)
 
         def seg(lo, hi, out):
             if lo == hi:
@@ -180,10 +195,11 @@ class GradReducer:
                 for g, gv in zip(gs, gviews[lo:hi]):
                     gv.zero_() if g is None else gv.copy_(g)
                 return
+            parts = [flat1d(g, c) for g, c in zip(gs, nhwc[lo:hi])]
             if gs[0].dtype == out.dtype:
-                torch.cat([g.reshape(-1) for g in gs], out=out)
+                torch.cat(parts, out=out)
             else:
-                out.copy_(torch.cat([g.reshape(-1) for g in gs]))
+                out.copy_(torch.cat(parts))
 
         seg(0, k, flat[:nw])
         seg(k, len(leaves), flat[nw:])

@@ -394,7 +394,7 @@ class ShapePropDecoder(nn.Module):
         if s_ == 1:
             y = F.conv2d(h, w, b, padding=1)
         elif s_ in (2, 4, 8) and Hin == H * s_ and h.shape[-1] == W * s_:
-            w4 = 0.25 * (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0)))
+            w4 = F.avg_pool2d(w, 2, stride=1, padding=1)   # mean of the four shifted 3x3 kernels (zero padded), one launch
             off = s_ // 2 - 2                      # first input row/col of the 4x4 window of output 0
             if off < 0:
                 y = F.conv2d(h, w4, b, stride=s_, padding=-off)
@@ -507,6 +507,7 @@ class CALayer(nn.Module):
         self.avg_pool = nn.AdaptiveAvgPool2d(1)
         self.conv_du = nn.Sequential(Conv2d(channel, channel // reduction, 1, bias=bias), nn.ReLU(inplace=True),
                                      Conv2d(channel // reduction, channel, 1, bias=bias), nn.Sigmoid())
+        self.conv_du[0].keep_master = self.conv_du[2].keep_master = True   # tiny fp32 MLP inside ops.ca_gate: no working copy
 
     def forward(self, x):
         return x * self.conv_du(self.avg_pool(x))
@@ -526,7 +527,7 @@ class CAB(nn.Module):
         act, du = self.body[1], self.CA.conv_du
         if x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and du[0].bias is None and du[2].bias is None:
             res = self.body[2](ops.prelu(self.body[0](x), act.weight))
-            return ops.ca_gate(res, x, wb(du[0])[0], wb(du[2])[0])     # gate * res + x in three launches
+            return ops.ca_gate(res, x, du[0].weight, du[2].weight)     # gate * res + x in three launches
         return self.CA(self.body(x)) + x
 
 
@@ -563,6 +564,11 @@ class _SpatialAttention(nn.Module):  # cod.py:390-405; constructed (cod.py:704),
 
 
 def _up(x, scale, align):
+    """Bilinear resize in the dtype of ``x``: under CUDA autocast the resampler would otherwise widen bf16 maps to fp32 and every
+    consumer (cat, conv, CAB) would cast them back."""
+    if x.is_cuda and x.dtype != torch.float32:
+        with torch.autocast("cuda", enabled=False):
+            return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align)
     return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align)
 
 

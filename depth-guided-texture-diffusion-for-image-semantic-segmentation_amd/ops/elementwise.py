@@ -23,15 +23,15 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return t
 
 
-def colsum(x2d: torch.Tensor) -> torch.Tensor:
-    """fp32 column sums of a [rows, C] matrix (bias gradients)."""
+def colsum(x2d: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Column sums of a [rows, C] matrix (bias gradients), accumulated in fp32 and written as ``out_dtype``."""
     L.check_cuda(x2d)
     rows, C = x2d.shape
     if C % (16 // x2d.element_size()):   # narrower than one 16-byte chunk per lane (e.g. a 1-wide head): generic device reduction
-        return x2d.sum(0, dtype=torch.float32)
-    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+        return x2d.sum(0, dtype=torch.float32).to(out_dtype)
+    out = torch.empty(C, dtype=out_dtype, device=x2d.device)
     ws = _workspace(L.load().dgtd_colsum_workspace(C), x2d.device)
-    L.call("dgtd_colsum", L.ptr(x2d), L.ptr(out), L.ptr(ws), rows, C, L.dtype_code(x2d), L.stream_ptr(),
+    L.call("dgtd_colsum", L.ptr(x2d), L.ptr(out), L.dtype_code(out), L.ptr(ws), rows, C, L.dtype_code(x2d), L.stream_ptr(),
            algo=("hbm", x2d.element_size() * x2d.numel()), key=f"dgtd_colsum[rows={rows},C={C}]")
     return out
 
@@ -96,7 +96,7 @@ def _wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     if S < 4 or M % S or dy2.dtype == torch.float32 or not SPLITK_WGRAD:
         return dy2.t() @ x2
     part = torch.bmm(dy2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1))
-    return part.sum(0, dtype=torch.float32).to(dy2.dtype)
+    return part.sum(0)      # bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
 
 
 class _LinearFn(Function):
@@ -134,7 +134,7 @@ class _LinearFn(Function):
         dy2 = dy2.contiguous()
         dx = (dy2 @ wc).view(xshape) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dy2, x2)
-        db = colsum(dy2).to(bdtype) if bdtype is not None else None
+        db = colsum(dy2, bdtype) if bdtype is not None else None
         return dx, (dw if dw.dtype == wdtype else dw.to(wdtype)), db
 
 

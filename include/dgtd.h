@@ -90,8 +90,10 @@ int64_t dgtd_colsum_workspace(int C);
 int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy,
                             float* dgamma, void* workspace, int64_t rows, int C, int64_t rows_per_sample,
                             dgtd_dtype dt, dgtd_stream st);
-/* out fp32 [C] = column sums of x [rows, C]: the bias gradient of nn.Linear (cod.py:829,832,872-875,1097,1099).        */
-int dgtd_colsum(const void* x, float* out, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st);
+/* out [C] (dtype out_dt, fp32 accumulation) = column sums of x [rows, C]: the bias gradient of nn.Linear
+ * (cod.py:829,832,872-875,1097,1099), written in the dtype of the bias it belongs to.                                   */
+int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt,
+                dgtd_stream st);
 
 /* ---- Fused structure loss of the five deep-supervision heads (fp32) -------------------------------
  * loss = sum_k mix[k] * cal_loss(bilinear_x(S/hs)(lo[k]), label): twig/model/cod.py:76-85 (weighted BCE + weighted IoU with

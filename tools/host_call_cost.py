@@ -43,6 +43,23 @@ with torch.no_grad():
     cost("F.conv2d 3x3 24->24 channels_last (MIOpen)", lambda: F.conv2d(xc, wc, None, padding=1))
     cost("torch elementwise add", lambda: x + x)
     cost("F.gelu", lambda: F.gelu(x))
+    for bm in (True, False):
+        torch.backends.cudnn.benchmark = bm
+        cost(f"F.conv2d 3x3 24->24 cudnn.benchmark={bm}", lambda: F.conv2d(xc, wc, None, padding=1))
+    torch.backends.cudnn.benchmark = False
+xcr = xc.clone().requires_grad_()
+wcr = wc.clone().requires_grad_()
+
+
+def conv_fb():
+    y = F.conv2d(xcr, wcr, None, padding=1)
+    y.backward(y)
+
+
+for bm in (False, True):
+    torch.backends.cudnn.benchmark = bm
+    cost(f"F.conv2d fwd+bwd cudnn.benchmark={bm}", conv_fb, 100)
+torch.backends.cudnn.benchmark = False
 xr = x.clone().requires_grad_()
 wr = w.clone().requires_grad_()
 br = b.clone().requires_grad_()

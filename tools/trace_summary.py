@@ -49,7 +49,8 @@ def main():
         else:
             groups[-1][1] = i
         prev = i
-    a, b = groups[-2][1] + 1, groups[-1][1] + 1
+    skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0   # bench.py: 2 instrumented steps
+    a, b = groups[-2 - skip][1] + 1, groups[-1 - skip][1] + 1
     t0, t1 = int(rows[a]["Start_Timestamp"]), int(rows[b - 1]["End_Timestamp"])
     agg = collections.defaultdict(lambda: [0, 0])
     busy = 0
