@@ -1,0 +1,397 @@
+// conv3x3.hip — dense 3x3 convolution (stride 1, zero padding 1) on NHWC bf16 maps with small channel counts (24..96), as
+// implicit GEMM on v_mfma_f32_32x32x16_bf16.  Serves the 16 prompt decoders (ShapePropDecoder, twig/model/cod.py:1216-1226: two
+// conv3x3 24->24 + ReLU per decoder at S/4) and the CAB bodies of the Hitnet decoder (cod.py:441-446: conv3x3 C->C, C in {32,64,96}).
+// Z independent convolutions (own weights / outputs, own or shared input) run in ONE launch (blockIdx.z).
+//
+//   forward      y[z,b,h,w,co] = act( sum_{ky,kx,ci} x[z|0,b,h+ky-1,w+kx-1,ci] * w[z,co,ky,kx,ci] + bias[z,co] )
+//   backward/x   the same kernel on dy with the transposed + spatially flipped kernel (conv3x3_flip_kernel); the ReLU of the
+//                forward is undone while the dy tile is staged (value kept where the saved forward output is > 0)
+//   backward/w   dw[z,co,ky,kx,ci] = sum_{b,h,w} dy[z,b,h,w,co] * x[z|0,b,h+ky-1,w+kx-1,ci]: pixels are the MFMA K dimension; both
+//                operands come from pixel-major LDS tiles through the transposing read (ds_read_b64_tr_b16), per-workgroup partial
+//                sums are reduced in a fixed order by conv3x3_wgrad_reduce_kernel, which also emits the bias gradient.
+//
+// Roofline: HBM.  Algorithmic bytes per convolution and direction = 2 B * B*H*W * (Ci + Co) (+ the mask map in the backward);
+// arithmetic intensity 9*Ci*Co/(Ci+Co) flop/B = 108 (24->24) .. 432 (96->96), far below the bf16 MFMA ridge (~300 flop/B only
+// reached by the 96-channel case), so the tiles are sized for load/store coalescing, not for MFMA occupancy.
+#include "common.h"
+
+namespace {
+
+typedef bf16x8 __attribute__((address_space(3))) * lds_v8;
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+  return v;
+}
+
+__device__ __forceinline__ bf16x8 load_masked(const bf16_t* __restrict__ src, const bf16_t* __restrict__ mask, size_t o) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(src + o);
+  if (mask) {
+    const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : (bf16_t)0.f;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / backward-data
+// Workgroup = 4 waves; tile = TWX columns x TH = 4*MT*(32/TWX) rows of output pixels; wave w owns MT m-tiles of 32 pixels
+// ((32/TWX) rows x TWX columns each).  The (TH+2) x (TWX+2) input halo tile is staged in LDS as [channel group of 8][pixel]
+// (16-byte elements): the MFMA B fragment of lane (pixel, k-half) is one conflict-free ds_read_b128.
+// K is the flattened (tap, channel group) index f in [0, 9*CI/8); MFMA step j covers f = 2j (lanes 0-31) and 2j+1 (lanes 32-63).
+// A = kernel rows (co), read from global/L2 (OHWI: 8 channels of one tap are 16 contiguous bytes), D[co][pixel].
+template <int CI, int NT, int MT, int TWX>
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ mask,
+                                                          const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                          bf16_t* __restrict__ y, int H, int W, int Co, int relu, int tiles_w,
+                                                          long x_zs, long w_zs, long y_zs) {
+  constexpr int G = CI / 8, RW = 32 / TWX, TH = 4 * MT * RW, LW = TWX + 2, LP = (TH + 2) * LW;
+  constexpr int NF = 9 * G, NSTEP = (NF + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* tile = reinterpret_cast<bf16x8*>(smem);   // [G][LP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w, b = blockIdx.y, z = blockIdx.z;
+  const int h0 = th * TH, w0 = tw * TWX;
+  const size_t img = (size_t)b * H * W;
+  const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
+  const bf16_t* mb = mask ? mask + (size_t)z * x_zs + img * CI : nullptr;
+  for (int c = tid; c < LP * G; c += 256) {
+    const int pix = c / G, g = c % G;
+    const int pr = pix / LW, pc = pix % LW;
+    const int h = h0 - 1 + pr, ww = w0 - 1 + pc;
+    bf16x8 v = zero8();
+    if (h >= 0 && h < H && ww >= 0 && ww < W) v = load_masked(xb, mb, ((size_t)h * W + ww) * CI + g * 8);
+    tile[g * LP + pix] = v;
+  }
+  __syncthreads();
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  const int pr = l31 / TWX, pc = l31 % TWX;
+  int basepix[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) basepix[mt] = ((wave * MT + mt) * RW + pr) * LW + pc;
+  const bf16_t* wz = w + (size_t)z * w_zs;
+  const bf16_t* wrow[NT];
+  bool wok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = nt * 32 + l31;
+    wok[nt] = co < Co;
+    wrow[nt] = wz + (size_t)(wok[nt] ? co : 0) * 9 * CI;
+  }
+#pragma unroll
+  for (int j = 0; j < NSTEP; ++j) {
+    const int f0 = 2 * j, f1 = (2 * j + 1 < NF) ? 2 * j + 1 : 2 * j;
+    const int tap0 = f0 / G, g0 = f0 % G, tap1 = f1 / G, g1 = f1 % G;
+    const int aoff = half ? g1 * LP + (tap1 / 3) * LW + tap1 % 3 : g0 * LP + (tap0 / 3) * LW + tap0 % 3;
+    const int woff = half ? tap1 * CI + g1 * 8 : tap0 * CI + g0 * 8;
+    const bool valid = half ? (2 * j + 1 < NF) : true;
+    bf16x8 wf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[nt] = (valid && wok[nt]) ? *reinterpret_cast<const bf16x8*>(wrow[nt] + woff) : zero8();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x8 xf = tile[basepix[mt] + aoff];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds pixel l31 of each m-tile; registers 4q..4q+3 = output channels 8q + 4*half + {0..3}
+  const bf16_t* bz = bias ? bias + (size_t)z * Co : nullptr;
+  bf16_t* yb = y + (size_t)z * y_zs + img * Co;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int h = h0 + (wave * MT + mt) * RW + pr, ww = w0 + pc;
+    if (h >= H || ww >= W) continue;
+    bf16_t* yp = yb + ((size_t)h * W + ww) * Co;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = nt * 32 + 8 * q + 4 * half;
+        if (co >= Co) continue;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[mt][nt][4 * q + e] + (bz ? (float)bz[co + e] : 0.f);
+          if (relu) v = fmaxf(v, 0.f);
+          o[e] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x4*>(yp + co) = o;
+      }
+  }
+}
+
+// w [Z][Co][3][3][Ci] -> wt [Z][Ci][3][3][Co], taps flipped: wt[z][ci][ky][kx][co] = w[z][co][2-ky][2-kx][ci]
+__global__ __launch_bounds__(256) void conv3x3_flip_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int Co, int Ci, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int co = (int)(i % Co);
+  long r = i / Co;
+  const int tap = (int)(r % 9);
+  r /= 9;
+  const int ci = (int)(r % Ci);
+  const long z = r / Ci;
+  wt[i] = w[((z * Co + co) * 9 + (8 - tap)) * Ci + ci];
+}
+
+// ------------------------------------------------------------------------------------------------ backward / weights
+constexpr int lds_stride_for(int c) {   // row stride (elements) of a pixel-major tile: >= roundup32(c) and == 32 mod 64, so that the
+  int s = (c + 31) / 32 * 32;           // 4 rows x 64 B a 32-lane half reads per transposing load fall into disjoint bank groups
+  return (s % 64 == 0) ? s + 32 : s;
+}
+
+// grid (P pixel splits, ceil(Co/32) output-channel tiles, Z).  Workgroup: 32 output channels x all 9*ceil(CI/32) (tap, 32-channel
+// block) tiles, distributed round-robin over the 4 waves; loops over its share of TH x TW pixel tiles, K = 16 pixels per MFMA.
+// partial [Z][MTt][P][32 co][9][CB*32 ci] fp32 (+ bias partial [Z][MTt][P][32]).
+template <int CI, int TH, int TW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                            const bf16_t* __restrict__ mask, float* __restrict__ partial,
+                                                            float* __restrict__ partial_b, int B, int H, int W, int Co,
+                                                            int tiles_w, int tiles_h, long x_zs, long dy_zs) {
+  constexpr int G = CI / 8, CB = (CI + 31) / 32, XS = lds_stride_for(CI), LW = TW + 2, LP = (TH + 2) * LW, NPIX = TH * TW;
+  constexpr int NTN = 9 * CB, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* xt = reinterpret_cast<bf16_t*>(smem);          // [LP][XS]
+  bf16_t* dt = xt + LP * XS;                             // [NPIX][32]
+  __shared__ float bred[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int p = blockIdx.x, P = gridDim.x, mt = blockIdx.y, MTt = gridDim.y, z = blockIdx.z;
+  const int ntiles = B * tiles_h * tiles_w;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bsum = 0.f;
+  if (CI % 32) {   // pad columns of the x tile are read by the transposing loads: keep them finite
+    for (int c = tid; c < LP * (CB * 32 - CI) / 8; c += 256) {
+      const int pix = c / ((CB * 32 - CI) / 8), g = c % ((CB * 32 - CI) / 8);
+      *reinterpret_cast<bf16x8*>(xt + pix * XS + CI + g * 8) = zero8();
+    }
+  }
+  for (int t = p; t < ntiles; t += P) {
+    const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, b = t / (tiles_w * tiles_h);
+    const int h0 = th * TH, w0 = tw * TW;
+    const size_t img = (size_t)b * H * W;
+    const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
+    const bf16_t* db = dy + (size_t)z * dy_zs + img * Co;
+    const bf16_t* mb = mask ? mask + (size_t)z * dy_zs + img * Co : nullptr;
+    __syncthreads();   // previous tile fully consumed
+    for (int c = tid; c < LP * G; c += 256) {
+      const int pix = c / G, g = c % G;
+      const int pr = pix / LW, pc = pix % LW;
+      const int h = h0 - 1 + pr, ww = w0 - 1 + pc;
+      bf16x8 v = zero8();
+      if (h >= 0 && h < H && ww >= 0 && ww < W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)h * W + ww) * CI + g * 8);
+      *reinterpret_cast<bf16x8*>(xt + pix * XS + g * 8) = v;
+    }
+    for (int c = tid; c < NPIX * 4; c += 256) {
+      const int pix = c >> 2, q = c & 3;
+      const int h = h0 + pix / TW, ww = w0 + pix % TW, co = mt * 32 + q * 8;
+      bf16x8 v = zero8();
+      if (h < H && ww < W && co < Co) v = load_masked(db, mb, ((size_t)h * W + ww) * Co + co);
+      *reinterpret_cast<bf16x8*>(dt + pix * 32 + q * 8) = v;
+    }
+    __syncthreads();
+    {   // bias gradient: thread (co = tid & 31, slice = tid >> 5) sums every 8th pixel of the dy tile
+      const int co = tid & 31, sl = tid >> 5;
+      float s = 0.f;
+      for (int pix = sl; pix < NPIX; pix += 8) s += (float)dt[pix * 32 + co];
+      bsum += s;
+    }
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+      const int r = ks / KPR, c0 = (ks % KPR) * 16;
+      const bf16x8 a = lds_tr_frag(dt, 32, r * TW + c0, 0, lane);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int tl = wave + 4 * i;
+        if (tl < NTN) {
+          const int tap = tl / CB, cb = tl % CB;
+          const bf16x8 bfr = lds_tr_frag(xt, XS, (r + tap / 3) * LW + c0 + tap % 3, cb * 32, lane);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* pp = partial + ((((size_t)z * MTt + mt) * P + p) * 32) * 9 * (CB * 32);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tl = wave + 4 * i;
+    if (tl < NTN) {
+      const int tap = tl / CB, cb = tl % CB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pp[((size_t)mfma_row(r, half) * 9 + tap) * (CB * 32) + cb * 32 + l31] = acc[i][r];
+    }
+  }
+  bred[tid >> 5][tid & 31] = bsum;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += bred[k][tid];
+    partial_b[(((size_t)z * MTt + mt) * P + p) * 32 + tid] = s;
+  }
+}
+
+// dw [Z][Co][9][CI] bf16 and db [Z][Co] bf16 from the partials (fixed summation order)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
+                                                                   bf16_t* __restrict__ dw, bf16_t* __restrict__ db, int Z, int Co,
+                                                                   int CI, int CB, int MTt, int P) {
+  const long n = (long)Z * Co * 9 * CI;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int ci = (int)(i % CI);
+    long r = i / CI;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int co = (int)(r % Co);
+    const long z = r / Co;
+    const int mt = co >> 5, cl = co & 31;
+    const float* pp = partial + (((size_t)z * MTt + mt) * P * 32 + cl) * 9 * (CB * 32) + (size_t)tap * (CB * 32) + ci;
+    const size_t ps = (size_t)32 * 9 * (CB * 32);
+    float s0 = 0.f, s1 = 0.f;
+    int q = 0;
+    for (; q + 1 < P; q += 2) { s0 += pp[q * ps]; s1 += pp[(q + 1) * ps]; }
+    if (q < P) s0 += pp[q * ps];
+    dw[i] = (bf16_t)(s0 + s1);
+  }
+  if (db && i < (long)Z * Co) {
+    const int co = (int)(i % Co);
+    const long z = i / Co;
+    const float* pb = partial_b + (((size_t)z * MTt + (co >> 5)) * P) * 32 + (co & 31);
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += pb[(size_t)q * 32];
+    db[i] = (bf16_t)s;
+  }
+}
+
+struct FwdGeom { int mt, twx; };
+
+inline FwdGeom fwd_geom(int Z, int B, int H, int W, int Ci) {
+  FwdGeom g;
+  g.twx = W >= 32 ? 32 : 16;
+  const int rw = 32 / g.twx;
+  // the largest tile that still gives >= 1024 workgroups (4 per CU), within 64 KB of LDS for the halo tile
+  const int mt_cap = Ci <= 32 ? 4 : (Ci <= 64 ? 2 : 1);
+  g.mt = 1;
+  for (int mt = mt_cap; mt > 1; mt >>= 1) {
+    const long wgs = (long)Z * B * cdiv(H, 4 * mt * rw) * cdiv(W, g.twx);
+    if (wgs >= 1024) { g.mt = mt; break; }
+  }
+  return g;
+}
+
+template <int CI, int NT, int MT, int TWX>
+int launch_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co, int relu,
+               int shared_x, hipStream_t st) {
+  constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2);
+  constexpr size_t lds = (size_t)(CI / 8) * LP * 16;
+  static_assert(lds <= 65536, "halo tile exceeds 64 KB of LDS");
+  const int tiles_w = (int)cdiv(W, TWX), tiles_h = (int)cdiv(H, TH);
+  const long plane = (long)B * H * W;
+  hipLaunchKernelGGL((conv3x3_fwd_kernel<CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z), dim3(256), lds, st, (const bf16_t*)x,
+                     (const bf16_t*)mask, (const bf16_t*)w, (const bf16_t*)bias, (bf16_t*)y, H, W, Co, relu, tiles_w,
+                     shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co);
+  DGTD_CHECK_LAUNCH("conv3x3_fwd");
+  return 0;
+}
+
+template <int CI, int NT>
+int dispatch_fwd_geom(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co,
+                      int relu, int shared_x, hipStream_t st) {
+  const FwdGeom g = fwd_geom(Z, B, H, W, CI);
+  if (g.twx == 16) return launch_fwd<CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+  if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
+  if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
+  return launch_fwd<CI, NT, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+}
+
+bool supported(int Ci, int Co) {
+  auto ok = [](int c) { return c == 24 || c == 32 || c == 64 || c == 96; };
+  return ok(Ci) && ok(Co);
+}
+
+template <int CI, int TH, int TW>
+int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* ws, int Z, int B, int H, int W, int Co,
+                 int shared_x, int P, hipStream_t st) {
+  constexpr int CB = (CI + 31) / 32, XS = lds_stride_for(CI), LP = (TH + 2) * (TW + 2);
+  constexpr size_t lds = ((size_t)LP * XS + (size_t)TH * TW * 32) * 2;
+  static_assert(lds <= 65536, "wgrad tiles exceed 64 KB of LDS");
+  const int tiles_w = (int)cdiv(W, TW), tiles_h = (int)cdiv(H, TH), MTt = (int)cdiv(Co, 32);
+  const long plane = (long)B * H * W;
+  float* partial = (float*)ws;
+  float* partial_b = partial + (size_t)Z * MTt * P * 32 * 9 * (CB * 32);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CI, TH, TW>), dim3(P, MTt, Z), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy,
+                     (const bf16_t*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
+  DGTD_CHECK_LAUNCH("conv3x3_wgrad");
+  const long n = (long)Z * Co * 9 * CI;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, (const float*)partial,
+                     (const float*)partial_b, (bf16_t*)dw, (bf16_t*)db, Z, Co, CI, CB, MTt, P);
+  DGTD_CHECK_LAUNCH("conv3x3_wgrad_reduce");
+  return 0;
+}
+
+inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
+  const int tw = W >= 32 ? 32 : 16, th = Ci >= 64 ? 4 : 8;
+  const long ntiles = (long)B * cdiv(H, th) * cdiv(W, tw);
+  const long want = std::max<long>(1, 1024 / ((long)Z * cdiv(Co, 32)));
+  return (int)std::max<long>(1, std::min<long>(std::min<long>(ntiles, want), 256));
+}
+
+}  // namespace
+
+extern "C" int dgtd_conv3x3_supported(int Ci, int Co, int H, int W) { return supported(Ci, Co) && H >= 1 && W >= 16 && W % 16 == 0; }
+
+extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
+                                int Ci, int Co, int relu, int shared_x, dgtd_stream s) {
+  DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad sizes");
+  DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
+  DGTD_REQUIRE(!(shared_x && mask), "conv3x3_fwd: a mask needs its own input per convolution");
+  hipStream_t st = (hipStream_t)s;
+  const int nt = (int)cdiv(Co, 32);
+#define DGTD_CONV_CASE(CI_, NT_) if (Ci == CI_ && nt == NT_) return dispatch_fwd_geom<CI_, NT_>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+  DGTD_CONV_CASE(24, 1) DGTD_CONV_CASE(24, 2) DGTD_CONV_CASE(24, 3)
+  DGTD_CONV_CASE(32, 1) DGTD_CONV_CASE(32, 2) DGTD_CONV_CASE(32, 3)
+  DGTD_CONV_CASE(64, 1) DGTD_CONV_CASE(64, 2) DGTD_CONV_CASE(64, 3)
+  DGTD_CONV_CASE(96, 1) DGTD_CONV_CASE(96, 2) DGTD_CONV_CASE(96, 3)
+#undef DGTD_CONV_CASE
+  DGTD_FAIL(2, "conv3x3_fwd: no kernel for Ci=%d Co=%d", Ci, Co);
+}
+
+extern "C" int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s) {
+  DGTD_REQUIRE(Z > 0 && Co > 0 && Ci > 0, "conv3x3_flip: bad sizes");
+  const long n = (long)Z * Co * 9 * Ci;
+  hipLaunchKernelGGL(conv3x3_flip_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)w, (bf16_t*)wt, Co, Ci, n);
+  DGTD_CHECK_LAUNCH("conv3x3_flip");
+  return 0;
+}
+
+extern "C" int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co) {
+  const int P = wgrad_splits(Z, B, H, W, Ci, Co), CB = (Ci + 31) / 32, MTt = (int)cdiv(Co, 32);
+  return (int64_t)Z * MTt * P * 32 * (9 * CB * 32 + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
+                                  int H, int W, int Ci, int Co, int shared_x, dgtd_stream s) {
+  DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_wgrad: bad sizes");
+  DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_wgrad: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
+  hipStream_t st = (hipStream_t)s;
+  const int P = wgrad_splits(Z, B, H, W, Ci, Co);
+  const bool wide = W >= 32;
+#define DGTD_WG_CASE(CI_, TH_) if (Ci == CI_) return wide ? launch_wgrad<CI_, TH_, 32>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st) \
+                                                         : launch_wgrad<CI_, TH_, 16>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st);
+  DGTD_WG_CASE(24, 8) DGTD_WG_CASE(32, 8) DGTD_WG_CASE(64, 4) DGTD_WG_CASE(96, 4)
+#undef DGTD_WG_CASE
+  DGTD_FAIL(2, "conv3x3_wgrad: no kernel for Ci=%d", Ci);
+}

@@ -144,6 +144,24 @@ int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const floa
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Dense 3x3 convolution, stride 1, zero padding 1, NHWC bf16, small channel counts ---------------------
+ * replaces the conv3x3(24->24)+ReLU pairs of the 16 prompt decoders (ShapePropDecoder, twig/model/cod.py:1216-1226, called at
+ * cod.py:1316-1323) and the conv3x3 C->C bodies of the Hitnet CABs (cod.py:441-446).  Z independent convolutions per launch:
+ * x [Z,B,H,W,Ci] (or [B,H,W,Ci] shared by all Z when shared_x != 0), w [Z,Co,3,3,Ci] (Conv2d weight in O,H,W,I order),
+ * bias [Z,Co] or NULL, y [Z,B,H,W,Co]; all bf16, fp32 accumulation.  Ci, Co in {24, 32, 64, 96}; W a multiple of 16.
+ * mask (NULL or the shape of x): x is taken as zero where mask <= 0 - the ReLU backward fused into the tile load.
+ * Backward w.r.t. x = dgtd_conv3x3_fwd on dy with the kernel from dgtd_conv3x3_flip (Ci and Co swapped, mask = forward output). */
+int dgtd_conv3x3_supported(int Ci, int Co, int H, int W);
+int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
+                     int Ci, int Co, int relu, int shared_x, dgtd_stream s);
+/* wt [Z,Ci,3,3,Co] = w [Z,Co,3,3,Ci] transposed, taps flipped.                                                                  */
+int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s);
+/* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) bf16, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).
+ * workspace: dgtd_conv3x3_wgrad_workspace(...) bytes of per-workgroup partial sums, reduced in a fixed order.                   */
+int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co);
+int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
+                       int H, int W, int Ci, int Co, int shared_x, dgtd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -258,3 +258,68 @@ def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
     wtol = 1e-4 if dtype == torch.float32 else 3e-2
     torch.testing.assert_close(hw1, gw1, atol=wtol * gw1.abs().max().item() + 1e-6, rtol=wtol)
     torch.testing.assert_close(hw2, gw2, atol=wtol * gw2.abs().max().item() + 1e-6, rtol=wtol)
+
+
+# ---------------------------------------------------------------------------------------------- dense 3x3 convolution (NHWC bf16 MFMA)
+def _conv_ref(x, w, b, relu):
+    y = F.conv2d(x.float(), w.float(), b.float() if b is not None else None, padding=1)
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 24, 24, 32, 32), (1, 24, 24, 40, 48), (2, 32, 32, 16, 16), (2, 64, 64, 32, 32),
+                                         (1, 96, 96, 64, 64), (2, 24, 64, 128, 128), (3, 64, 32, 24, 32), (8, 24, 24, 128, 128)])
+@pytest.mark.parametrize("relu,bias", [(True, True), (False, False)])
+def test_conv3x3_single_fwd_bwd(dgtd, B, C, Co, H, W, relu, bias):
+    """One convolution: forward, input gradient (through the fused ReLU mask), weight and bias gradients vs fp32 torch."""
+    x = _rand(B, C, H, W, seed=1, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (_rand(Co, C, 3, 3, seed=2) / math.sqrt(9 * C)).to(torch.bfloat16)
+    b = (0.1 * _rand(Co, seed=3)).to(torch.bfloat16) if bias else None
+    g = _rand(B, Co, H, W, seed=4, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    br = b.float().requires_grad_() if bias else None
+    ref = _conv_ref(xr, wr, br, relu)
+    grads = torch.autograd.grad(ref, (xr, wr) + ((br,) if bias else ()), g.float())
+    xs, wsn = x.clone().requires_grad_(), w.clone().requires_grad_()
+    bs = b.clone().requires_grad_() if bias else None
+    y = dgtd.ops.conv3x3(xs, wsn, bs, relu)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
+    # the ReLU mask is taken from the bf16 output: compare gradients where the fp32 reference is not within rounding of 0
+    got = torch.autograd.grad(y, (xs, wsn) + ((bs,) if bias else ()), g)
+    if relu:   # reference gradients with the mask of the bf16 output, so a pre-activation that rounds across 0 does not count as an error
+        ref2 = F.conv2d(xr, wr, br, padding=1)
+        grads = torch.autograd.grad(ref2, (xr, wr) + ((br,) if bias else ()), g.float() * (y.float() > 0))
+    torch.testing.assert_close(got[0].float(), grads[0], atol=3e-2, rtol=3e-2)
+    n = B * H * W
+    torch.testing.assert_close(got[1].float(), grads[1], atol=2e-2 * math.sqrt(n), rtol=3e-2)
+    if bias:
+        torch.testing.assert_close(got[2].float(), grads[2], atol=2e-2 * math.sqrt(n), rtol=3e-2)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_conv3x3_stack_matches_separate_convs(dgtd, shared):
+    """Z = 5 convolutions in one launch (shared or own inputs) == Z separate fp32 convolutions, incl. the summed shared-input grad."""
+    Z, B, C, H, W = 5, 2, 24, 32, 48
+    xs = [_rand(B, H, W, C, seed=10 + z, dtype=torch.bfloat16) for z in range(1 if shared else Z)]
+    ws = [(_rand(C, C, 3, 3, seed=20 + z) / math.sqrt(9 * C)).to(torch.bfloat16).requires_grad_() for z in range(Z)]
+    bs = [(0.1 * _rand(C, seed=30 + z)).to(torch.bfloat16).requires_grad_() for z in range(Z)]
+    g = _rand(Z, B, H, W, C, seed=5, dtype=torch.bfloat16)
+    xin = (xs[0] if shared else torch.stack(xs)).clone().requires_grad_()
+    y = dgtd.ops.conv3x3_stack(xin, ws, bs, True)
+    assert y.shape == (Z, B, H, W, C)
+    got = torch.autograd.grad(y, [xin] + ws + bs, g)
+    dx_ref = torch.zeros_like(xin, dtype=torch.float32)
+    for z in range(Z):
+        xr = (xs[0] if shared else xs[z]).float().permute(0, 3, 1, 2).requires_grad_()
+        wr, br = ws[z].detach().float().requires_grad_(), bs[z].detach().float().requires_grad_()
+        pre = F.conv2d(xr, wr, br, padding=1)
+        torch.testing.assert_close(y[z].float(), F.relu(pre).permute(0, 2, 3, 1), atol=2e-2, rtol=2e-2)
+        gz = g[z].float().permute(0, 3, 1, 2) * (y[z].float().permute(0, 3, 1, 2) > 0)
+        dx, dw, db = torch.autograd.grad(pre, (xr, wr, br), gz)
+        if shared:
+            dx_ref += dx.permute(0, 2, 3, 1)
+        else:
+            dx_ref[z] = dx.permute(0, 2, 3, 1)
+        torch.testing.assert_close(got[1 + z].float(), dw, atol=2e-2 * math.sqrt(B * H * W), rtol=3e-2)
+        torch.testing.assert_close(got[1 + Z + z].float(), db, atol=2e-2 * math.sqrt(B * H * W), rtol=3e-2)
+    torch.testing.assert_close(got[0].float(), dx_ref, atol=6e-2 if shared else 3e-2, rtol=3e-2)
