@@ -46,6 +46,8 @@ SIGNATURES = {
     "dgtd_prelu_fwd": (_i, [_vp, _fp, _vp, _i64, _i, _vp]),
     "dgtd_prelu_bwd": (_i, [_vp, _vp, _fp, _vp, _fp, _i64, _i, _vp]),
     "dgtd_ca_gate_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_supported": (_i, [_i, _i, _i, _i]),
     "dgtd_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_flip": (_i, [_vp, _vp, _i, _i, _i, _vp]),

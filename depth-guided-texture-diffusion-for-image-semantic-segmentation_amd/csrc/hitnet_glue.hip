@@ -160,6 +160,104 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const T* __restrict__
   }
 }
 
+
+// ---- bilinear resize of NHWC maps (F.interpolate(mode="bilinear"), both align_corners conventions; cod.py:757-789 uses
+// align_corners=True x2 / x4 / x0.5 between the decoder levels).  The backward is a GATHER over the output pixels that touch an
+// input pixel (deterministic, no atomics): torch's NHWC bf16 backward scatters with atomics and costs 190 us per call here.
+struct Axis { float scale; int align; };
+__device__ __forceinline__ float src_index(int o, Axis a) {
+  if (a.align) return a.scale * (float)o;
+  const float s = a.scale * ((float)o + 0.5f) - 0.5f;
+  return s < 0.f ? 0.f : s;
+}
+__device__ __forceinline__ void taps(int o, Axis a, int n_in, int& i0, int& i1, float& l1) {
+  const float s = src_index(o, a);
+  i0 = min((int)s, n_in - 1);
+  i1 = min(i0 + 1, n_in - 1);
+  l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo,
+                                                           int C, Axis ah, Axis aw) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t r = i / CV;
+    const int ow = (int)(r % Wo);
+    r /= Wo;
+    const int oh = (int)(r % Ho), b = (int)(r / Ho);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    taps(oh, ah, Hi, h0, h1, lh);
+    taps(ow, aw, Wi, w0, w1, lw);
+    const T* xb = x + (size_t)b * Hi * Wi * C + cv * V;
+    const VT v00 = *reinterpret_cast<const VT*>(xb + ((size_t)h0 * Wi + w0) * C), v01 = *reinterpret_cast<const VT*>(xb + ((size_t)h0 * Wi + w1) * C);
+    const VT v10 = *reinterpret_cast<const VT*>(xb + ((size_t)h1 * Wi + w0) * C), v11 = *reinterpret_cast<const VT*>(xb + ((size_t)h1 * Wi + w1) * C);
+    VT o;
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      o[e] = (T)((1.f - lh) * ((1.f - lw) * (float)v00[e] + lw * (float)v01[e]) + lh * ((1.f - lw) * (float)v10[e] + lw * (float)v11[e]));
+    *reinterpret_cast<VT*>(y + i * V) = o;
+  }
+}
+
+// weight with which output index o reads input index i along one axis (0 when it does not)
+__device__ __forceinline__ float tap_weight(int o, int i, Axis a, int n_in) {
+  int i0, i1;
+  float l1;
+  taps(o, a, n_in, i0, i1, l1);
+  return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo,
+                                                           int C, Axis ah, Axis aw, float inv_h, float inv_w) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V;
+  const int64_t n = (int64_t)B * Hi * Wi * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t r = i / CV;
+    const int iw = (int)(r % Wi);
+    r /= Wi;
+    const int ih = (int)(r % Hi), b = (int)(r / Hi);
+    // conservative candidate ranges: outputs whose source coordinate can lie within (i-1, i+1)
+    const int oh_lo = max(0, (int)floorf(((float)ih - 1.f) * inv_h) - 1), oh_hi = min(Ho - 1, (int)ceilf(((float)ih + 1.f) * inv_h) + 1);
+    const int ow_lo = max(0, (int)floorf(((float)iw - 1.f) * inv_w) - 1), ow_hi = min(Wo - 1, (int)ceilf(((float)iw + 1.f) * inv_w) + 1);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const T* gb = dy + (size_t)b * Ho * Wo * C + cv * V;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const float wy = tap_weight(oh, ih, ah, Hi);
+      if (wy == 0.f) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const float wgt = wy * tap_weight(ow, iw, aw, Wi);
+        if (wgt == 0.f) continue;
+        const VT g = *reinterpret_cast<const VT*>(gb + ((size_t)oh * Wo + ow) * C);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += wgt * (float)g[e];
+      }
+    }
+    VT o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = (T)acc[e];
+    *reinterpret_cast<VT*>(dx + i * V) = o;
+  }
+}
+
+inline Axis make_axis(int n_in, int n_out, int align) {
+  Axis a;
+  a.align = align;
+  a.scale = align ? (n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f) : (float)n_in / (float)n_out;
+  return a;
+}
+
 inline int ew_grid(int64_t items) { return (int)std::min<int64_t>(cdiv(items, 256), 2048); }
 
 }  // namespace
@@ -225,5 +323,33 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C);
   else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C);
   DGTD_CHECK_LAUNCH("ca_apply_bwd");
+  return 0;
+}
+
+extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
+                                 dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_fwd: bad sizes (C=%d must be a multiple of %d)", C, V);
+  const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);
+  const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
+  else if (dt == DGTD_F32) hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
+  else DGTD_FAIL(2, "bilinear_fwd: bad dtype %d", (int)dt);
+  DGTD_CHECK_LAUNCH("bilinear_fwd");
+  return 0;
+}
+
+extern "C" int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
+                                 dgtd_stream s) {
+  const int V = dt == DGTD_BF16 ? 8 : 4;
+  DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_bwd: bad sizes (C=%d must be a multiple of %d)", C, V);
+  const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);
+  // d(src)/d(out index) = scale, so an input pixel i is touched by outputs around i / scale
+  const float inv_h = ah.scale > 0.f ? 1.f / ah.scale : (float)Ho, inv_w = aw.scale > 0.f ? 1.f / aw.scale : (float)Wo;
+  const int grid = ew_grid((int64_t)B * Hi * Wi * (C / V));
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
+  else if (dt == DGTD_F32) hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
+  else DGTD_FAIL(2, "bilinear_bwd: bad dtype %d", (int)dt);
+  DGTD_CHECK_LAUNCH("bilinear_bwd");
   return 0;
 }

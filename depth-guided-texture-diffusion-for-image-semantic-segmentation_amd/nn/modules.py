@@ -8,6 +8,7 @@ Reference citations are to /root/reference/twig/model/cod.py.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -17,6 +18,8 @@ import torch.nn.functional as F
 from .. import ops
 
 LATENT = 24
+# A/B switches for tools/ and bench runs (default: every native path on)
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -381,12 +384,13 @@ class ShapePropDecoder(nn.Module):
     def forward(self, embedding):
         return self.decoder(embedding)
 
-    def forward_tokens(self, embedding, H, W):
+    def forward_tokens(self, embedding, H, W, trunk=None):
         """== F.interpolate(self.decoder(embedding), (H, W), 'bilinear') as tokens [B, H*W, C] (cod.py:1471), without ever
         materialising the full-resolution prompt: for an integer power-of-two down-scale s the align_corners=False bilinear
         sample is the mean of the 2x2 centre pixels, and mean-of-conv3x3 == one 4x4 convolution with stride s whose
         kernel is the mean of the four shifted 3x3 kernels (zero padding carries over unchanged)."""
-        h = self.decoder[3](self.decoder[2](self.decoder[1](self.decoder[0](embedding))))
+        # ``trunk``: the output of the two conv3x3+ReLU layers, NHWC, when the caller ran them for all decoders in one launch
+        h = trunk.permute(0, 3, 1, 2) if trunk is not None else self.decoder[3](self.decoder[2](self.decoder[1](self.decoder[0](embedding))))
         conv = self.decoder[4]
         w, b = wb(conv)
         Hin = h.shape[-2]
@@ -416,8 +420,8 @@ class prompt_decoder(nn.Module):
     def forward(self, embedding, cross=False):
         return [self.decoder[i](embedding) for i in range(self.depth)]
 
-    def forward_tokens(self, embedding, H, W):
-        return [self.decoder[i].forward_tokens(embedding, H, W) for i in range(self.depth)]
+    def forward_tokens(self, embedding, H, W, trunks=None):
+        return [self.decoder[i].forward_tokens(embedding, H, W, None if trunks is None else trunks[i]) for i in range(self.depth)]
 
 
 class PyramidVisionTransformerImpr(nn.Module):
@@ -453,16 +457,33 @@ class PyramidVisionTransformerImpr(nn.Module):
         image = x
         embedding1, embedding3 = self.prompt_encoder(image, depth, x_hp=x_hp)
         embedding3 = embedding3.contiguous(memory_format=torch.channels_last)
+        trunks, off = self._prompt_trunks(embedding3), 0
         outs = []
         for i in range(4):
             x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
-            prompts = self.prompt_decoder[i].forward_tokens(embedding3, H, W)   # already at (H, W), already tokens
+            d = self.prompt_decoder[i].depth
+            prompts = self.prompt_decoder[i].forward_tokens(embedding3, H, W, None if trunks is None else trunks[off:off + d])
+            off += d                                                            # prompts: already at (H, W), already tokens
             for j, blk in enumerate(getattr(self, f"block{i + 1}")):
                 x = blk(x + prompts[j], H, W)
             x = getattr(self, f"norm{i + 1}")(x)
             x = _tokens_to_nchw(x, H, W)   # channels_last view: feeds the next patch embed and the Hitnet decoder as is
             outs.append(x)
         return embedding1, outs
+
+    def _prompt_trunks(self, embedding):
+        """The two conv3x3(24->24)+ReLU layers of ALL prompt decoders (cod.py:1216-1220; 16 for pvt_v2_b2) as two launches of the
+        batched NHWC MFMA kernel: the first reads the shared embedding once per tile, the second maps [Z,B,h,w,24] -> same.
+        Returns NHWC [Z,B,h,w,24], or None when the geometry / dtype is outside the kernel (fp32 parity mode, CPU)."""
+        decs = [d for pd in self.prompt_decoder for d in pd.decoder]
+        c0, c1 = [d.decoder[0] for d in decs], [d.decoder[2] for d in decs]
+        w0 = [wb(c)[0] for c in c0]
+        B, C, H, W = embedding.shape
+        if not (_USE["conv3x3"] and ops.conv3x3_ops.supported(embedding, C, C, H, W) and all(w.dtype == embedding.dtype for w in w0)):
+            return None
+        x = embedding.permute(0, 2, 3, 1).contiguous()
+        h = ops.conv3x3_stack(x, w0, [wb(c)[1] for c in c0], True)
+        return ops.conv3x3_stack(h, [wb(c)[0] for c in c1], [wb(c)[1] for c in c1], True)
 
     def forward(self, x, depth, x_hp=None):
         return self.forward_features(x, depth, x_hp)
@@ -525,7 +546,7 @@ class CAB(nn.Module):
 
     def forward(self, x):
         act, du = self.body[1], self.CA.conv_du
-        if x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and du[0].bias is None and du[2].bias is None:
+        if _USE["cab_glue"] and x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and du[0].bias is None and du[2].bias is None:
             res = self.body[2](ops.prelu(self.body[0](x), act.weight))
             return ops.ca_gate(res, x, du[0].weight, du[2].weight)     # gate * res + x in three launches
         return self.CA(self.body(x)) + x
@@ -566,6 +587,8 @@ class _SpatialAttention(nn.Module):  # cod.py:390-405; constructed (cod.py:704),
 def _up(x, scale, align):
     """Bilinear resize in the dtype of ``x``: under CUDA autocast the resampler would otherwise widen bf16 maps to fp32 and every
     consumer (cat, conv, CAB) would cast them back."""
+    if _USE["bilinear"] and x.is_cuda and x.shape[1] % (16 // x.element_size()) == 0:
+        return ops.bilinear_resize(x, int(math.floor(x.shape[2] * scale)), int(math.floor(x.shape[3] * scale)), align)
     if x.is_cuda and x.dtype != torch.float32:
         with torch.autocast("cuda", enabled=False):
             return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align)

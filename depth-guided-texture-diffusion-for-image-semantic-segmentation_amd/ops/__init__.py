@@ -9,5 +9,5 @@ from .dwconv import dwconv_nhwc  # noqa: F401
 from .elementwise import colsum, linear, scale_residual  # noqa: F401
 from . import conv3x3 as conv3x3_ops  # noqa: F401
 from .conv3x3 import conv3x3, conv3x3_stack  # noqa: F401
-from .hitnet import ca_gate, prelu  # noqa: F401
+from .hitnet import bilinear_resize, ca_gate, prelu  # noqa: F401
 from .loss import seg_loss  # noqa: F401

@@ -98,3 +98,31 @@ def ca_gate(res: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, w2: torch.Tens
     """res * sigmoid(conv1x1_w2(relu(conv1x1_w1(avgpool(res))))) + x — CALayer (cod.py:428-431) and the CAB residual (cod.py:451).
     w1 [C/r, C, 1, 1], w2 [C, C/r, 1, 1] are the bias-free conv_du weights (cod.py:421-425)."""
     return _CAGateFn.apply(res, x, w1, w2)
+
+
+class _BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        _require_cuda(x)
+        x = _nhwc(x)
+        B, C, Hi, Wi = x.shape
+        y = torch.empty(B, C, Ho, Wo, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.call("dgtd_bilinear_fwd", L.ptr(x), L.ptr(y), B, Hi, Wi, Ho, Wo, C, int(align), L.dtype_code(x), L.stream_ptr(),
+               algo=("hbm", x.element_size() * (x.numel() + y.numel())), key=f"dgtd_bilinear_fwd[{Hi}x{Wi}->{Ho}x{Wo},C={C}]")
+        ctx.meta = (B, C, Hi, Wi, Ho, Wo, align, x.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, C, Hi, Wi, Ho, Wo, align, dtype = ctx.meta
+        g = _nhwc(g if g.dtype == dtype else g.to(dtype))
+        dx = torch.empty(B, C, Hi, Wi, dtype=dtype, device=g.device, memory_format=torch.channels_last)
+        L.call("dgtd_bilinear_bwd", L.ptr(g), L.ptr(dx), B, Hi, Wi, Ho, Wo, C, int(align), L.dtype_code(g), L.stream_ptr(),
+               algo=("hbm", g.element_size() * (g.numel() + dx.numel())), key=f"dgtd_bilinear_bwd[{Hi}x{Wi}<-{Ho}x{Wo},C={C}]")
+        return dx, None, None, None
+
+
+def bilinear_resize(x: torch.Tensor, out_h: int, out_w: int, align_corners: bool) -> torch.Tensor:
+    """F.interpolate(x, size=(out_h, out_w), mode="bilinear", align_corners=...) for a logical [B,C,H,W] map kept channels_last."""
+    return _BilinearFn.apply(x, int(out_h), int(out_w), bool(align_corners))

@@ -144,6 +144,14 @@ int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const floa
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 
+/* Bilinear resize of an NHWC map, x [B,Hi,Wi,C] -> y [B,Ho,Wo,C]: F.interpolate(mode="bilinear") with either align_corners
+ * convention - the x2 / x4 / x0.5 align_corners=True resizes between the Hitnet decoder levels (cod.py:757-789).  The backward
+ * gathers, for every input pixel, the output pixels that read it (dx overwritten, no atomics).                               */
+int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                      dgtd_dtype dt, dgtd_stream s);
+int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                      dgtd_dtype dt, dgtd_stream s);
+
 /* ---- Dense 3x3 convolution, stride 1, zero padding 1, NHWC bf16, small channel counts ---------------------
  * replaces the conv3x3(24->24)+ReLU pairs of the 16 prompt decoders (ShapePropDecoder, twig/model/cod.py:1216-1226, called at
  * cod.py:1316-1323) and the conv3x3 C->C bodies of the Hitnet CABs (cod.py:441-446).  Z independent convolutions per launch:

@@ -323,3 +323,23 @@ def test_conv3x3_stack_matches_separate_convs(dgtd, shared):
         torch.testing.assert_close(got[1 + z].float(), dw, atol=2e-2 * math.sqrt(B * H * W), rtol=3e-2)
         torch.testing.assert_close(got[1 + Z + z].float(), db, atol=2e-2 * math.sqrt(B * H * W), rtol=3e-2)
     torch.testing.assert_close(got[0].float(), dx_ref, atol=6e-2 if shared else 3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 32, 16, 16, 32, 32), (2, 32, 16, 16, 64, 64), (1, 64, 24, 20, 48, 40), (2, 32, 128, 128, 64, 64),
+                                             (2, 8, 7, 9, 19, 13), (1, 96, 32, 32, 64, 64)])
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bilinear_resize_nhwc(dgtd, B, C, Hi, Wi, Ho, Wo, align, dtype):
+    """Forward and gather-backward vs F.interpolate in fp32 (x2, x4, x0.5 and a ragged non-integer ratio)."""
+    x = _rand(B, C, Hi, Wi, seed=1, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    g = _rand(B, C, Ho, Wo, seed=2, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_()
+    ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=align)
+    gx, = torch.autograd.grad(ref, xr, g.float())
+    xs = x.clone().requires_grad_()
+    y = dgtd.ops.bilinear_resize(xs, Ho, Wo, align)
+    hx, = torch.autograd.grad(y, xs, g)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol * 8, rtol=tol)

@@ -16,7 +16,7 @@ torch.manual_seed(0)
 net = dgtd.nn.cod(compute_dtype=torch.bfloat16).to(dev).train()
 red = dgtd.dist.GradReducer(net, working_dtype=torch.bfloat16)
 opt = dgtd.runner.build_optimizer(net)
-data = dgtd.runner.SyntheticRGBD(512, 8, device=dev)
+data = dgtd.runner.SyntheticRGBD(int(os.environ.get("SIZE", 512)), 8, device=dev)
 b = data.batch_at(0)
 
 
