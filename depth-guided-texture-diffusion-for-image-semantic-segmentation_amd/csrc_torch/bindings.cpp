@@ -8,6 +8,7 @@
 #include <torch/library.h>
 
 #include "../../include/dgtd.h"
+#include "gemm.h"
 
 namespace {
 
@@ -201,11 +202,15 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     oshape.back() = w.size(0);
     Tensor out = at::empty(oshape, x.options().dtype(dt));
     Tensor o2 = out.view({-1, w.size(0)});
-    if (has_b) {
-      Tensor bc = b_->scalar_type() == dt ? *b_ : b_->to(dt);
-      at::addmm_out(o2, bc, x2, wc.t());
-    } else {
-      at::mm_out(o2, x2, wc.t());
+    Tensor bc;
+    if (has_b) bc = b_->scalar_type() == dt ? b_->contiguous() : b_->to(dt);
+    const int64_t M = x2.size(0), K = x2.size(1), N = w.size(0);
+    const bool direct = dt == at::kBFloat16 && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
+                        dgemm::matmul_bf16(x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), has_b ? bc.data_ptr() : nullptr, M, N, K, false, true,
+                                           1, 0, 0, 0, x2.options(), (hipStream_t)stream());
+    if (!direct) {
+      if (has_b) at::addmm_out(o2, bc, x2, wc.t());
+      else at::mm_out(o2, x2, wc.t());
     }
     ctx->save_for_backward({x2, wc});
     ctx->saved_data["xshape"] = x.sizes().vec();
@@ -221,17 +226,30 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     if (dy2.scalar_type() != x2.scalar_type()) dy2 = dy2.to(x2.scalar_type());
     dy2 = dy2.contiguous();
     Tensor dx;
-    if (ctx->saved_data["need_dx"].toBool()) dx = at::mm(dy2, wc).view(ctx->saved_data["xshape"].toIntVector());
+    const int64_t Mr = dy2.size(0), Nw = wc.size(0), Kw = wc.size(1);
+    const bool bf = dy2.scalar_type() == at::kBFloat16 && x2.is_contiguous() && wc.is_contiguous() && Mr > 0;
+    hipStream_t st = (hipStream_t)stream();
+    if (ctx->saved_data["need_dx"].toBool()) {
+      Tensor dx2 = at::empty({Mr, Kw}, dy2.options());
+      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, Mr, Kw, Nw, false, false, 1, 0, 0, 0, dy2.options(), st)))
+        at::mm_out(dx2, dy2, wc);
+      dx = dx2.view(ctx->saved_data["xshape"].toIntVector());
+    }
     // dW = dY^T X; long token dimensions are split into S batches (library batched GEMM) and summed in fp32: the plain GEMM has
     // only a few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
     const int64_t M = dy2.size(0);
     const int64_t S = std::min<int64_t>(32, M / 1024);
     Tensor dw;
     if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
-      Tensor part = at::bmm(dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
+      Tensor part = at::empty({S, Nw, Kw}, dy2.options());
+      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, Nw, Kw, M / S, true, false, (int)S,
+                                     (M / S) * Nw, (M / S) * Kw, Nw * Kw, dy2.options(), st)))
+        at::bmm_out(part, dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
       dw = at::sum(part, {0});   // bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
     } else {
-      dw = at::mm(dy2.t(), x2);
+      dw = at::empty({Nw, Kw}, dy2.options());
+      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, Nw, Kw, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
+        at::mm_out(dw, dy2.t(), x2);
     }
     const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
     if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);

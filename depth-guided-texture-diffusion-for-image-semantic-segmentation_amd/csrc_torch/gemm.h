@@ -1,0 +1,121 @@
+// gemm.h — bf16 GEMMs of the Linear layers through hipBLASLt with CACHED plans.
+// at::mm / at::addmm re-create the matmul descriptor and re-run hipblasLtMatmulAlgoGetHeuristic on every call (18.5 us of host
+// time per GEMM, tools/host_call_cost.py; 543 GEMMs per training step).  Here a plan (descriptor, layouts, heuristic algorithm)
+// is built once per (shape, transposes, epilogue, batch) and per thread (forward runs on the Python thread, backward on autograd's
+// device thread), so a call is one hipblasLtMatmul.  Library GEMM, not a hand-written kernel: plain GEMMs belong to hipBLASLt.
+#pragma once
+#include <ATen/ATen.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <cstdlib>
+#include <unordered_map>
+
+namespace dgemm {
+
+struct Key {
+  int64_t m, n, k, sa, sb, sd;
+  int ta, tb, bias, batch;
+  bool operator==(const Key& o) const {
+    return m == o.m && n == o.n && k == o.k && sa == o.sa && sb == o.sb && sd == o.sd && ta == o.ta && tb == o.tb && bias == o.bias &&
+           batch == o.batch;
+  }
+};
+struct KeyHash {
+  size_t operator()(const Key& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int64_t v : {k.m, k.n, k.k, k.sa, k.sb, k.sd, (int64_t)k.ta, (int64_t)k.tb, (int64_t)k.bias, (int64_t)k.batch}) {
+      h ^= (size_t)v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    }
+    return h;
+  }
+};
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  bool ok = false;
+};
+struct Ctx {
+  hipblasLtHandle_t handle = nullptr;
+  hipblasLtMatmulPreference_t pref = nullptr;
+  std::unordered_map<Key, Plan, KeyHash> plans;
+  at::Tensor ws;
+  bool dead = false;
+};
+constexpr size_t kWorkspace = 64u << 20;
+
+inline bool enabled() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_DIRECT_GEMM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+inline Ctx& ctx() {
+  thread_local Ctx c;
+  return c;
+}
+
+inline bool ok(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS; }
+
+inline void set_batch(hipblasLtMatrixLayout_t l, int32_t batch, int64_t stride) {
+  hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch));
+  hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &stride, sizeof(stride));
+}
+
+// D[batch][M][N] (row-major) = op(A) op(B) (+ bias[N]);  A is [M,K] (transA: [K,M]), B is [K,N] (transB: [N,K]), all bf16, dense.
+// Returns false when hipBLASLt offers no algorithm for the problem: the caller then uses the ATen GEMM.
+inline bool matmul_bf16(const void* A, const void* B, void* D, const void* bias, int64_t M, int64_t N, int64_t K, bool transA,
+                        bool transB, int batch, int64_t sA, int64_t sB, int64_t sD, const at::TensorOptions& dev_opts, hipStream_t st) {
+  if (!enabled()) return false;
+  Ctx& c = ctx();
+  if (c.dead) return false;
+  if (!c.handle) {
+    uint64_t wsz = kWorkspace;
+    if (!ok(hipblasLtCreate(&c.handle)) || !ok(hipblasLtMatmulPreferenceCreate(&c.pref)) ||
+        !ok(hipblasLtMatmulPreferenceSetAttribute(c.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)))) {
+      c.dead = true;
+      return false;
+    }
+    c.ws = at::empty({(int64_t)kWorkspace}, dev_opts.dtype(at::kByte));
+  }
+  const Key key{M, N, K, sA, sB, sD, (int)transA, (int)transB, bias ? 1 : 0, batch};
+  auto it = c.plans.find(key);
+  if (it == c.plans.end()) {
+    Plan p;
+    // column-major view of the row-major problem: D^T (N x M) = op(B)^T-as-stored ... i.e. blas A := B memory, blas B := A memory
+    const hipblasOperation_t opA = transB ? HIPBLAS_OP_T : HIPBLAS_OP_N, opB = transA ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    bool good = ok(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    good = good && ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opA, sizeof(int32_t)));
+    good = good && ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opB, sizeof(int32_t)));
+    if (good && bias) {
+      const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+      const int32_t bt = (int32_t)HIP_R_16BF;
+      good = ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi))) &&
+             ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt))) &&
+             ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(void*)));
+    }
+    good = good && ok(transB ? hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, K, N, K) : hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, N, K, N));
+    good = good && ok(transA ? hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, M, K, M) : hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, K, M, K));
+    good = good && ok(hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, N, M, N));
+    if (good && batch > 1) {
+      set_batch(p.a, batch, sB);
+      set_batch(p.b, batch, sA);
+      set_batch(p.d, batch, sD);
+    }
+    if (good) {
+      hipblasLtMatmulHeuristicResult_t res[1];
+      int found = 0;
+      good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, 1, res, &found)) && found > 0 &&
+             res[0].workspaceSize <= kWorkspace;
+      if (good) p.algo = res[0].algo;
+    }
+    p.ok = good;
+    it = c.plans.emplace(key, p).first;
+  }
+  Plan& p = it->second;
+  if (!p.ok) return false;
+  if (bias && !ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(void*)))) return false;
+  const float alpha = 1.f, beta = 0.f;
+  return ok(hipblasLtMatmul(c.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, D, p.d, D, p.d, &p.algo, c.ws.data_ptr(), kWorkspace, st));
+}
+
+}  // namespace dgemm
