@@ -260,6 +260,166 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
   }
 };
 
+
+// ------------------------------------------------------------------------------------------------ dense conv3x3 (NHWC bf16 MFMA)
+// raw form: x [Z|1,B,H,W,Ci], w [Z,Co,3,3,Ci], b [Z,Co]? -> y [Z,B,H,W,Co]
+struct ConvGeom { int Z, B, H, W, Ci, Co; bool shared; };
+inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor& y_mask, const Tensor& dy, const ConvGeom& g, bool need_dx,
+                                 bool has_b, Tensor& dx, Tensor& dw, Tensor& db) {
+  const void* mask = y_mask.defined() ? y_mask.data_ptr() : nullptr;
+  if (need_dx) {
+    Tensor wt = at::empty({g.Z, g.Ci, 3, 3, g.Co}, w.options());
+    check(dgtd_conv3x3_flip(w.data_ptr(), wt.data_ptr(), g.Z, g.Co, g.Ci, stream()), "dgtd_conv3x3_flip");
+    check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, stream()),
+          "dgtd_conv3x3_fwd (input gradient)");
+  }
+  Tensor ws = at::empty({dgtd_conv3x3_wgrad_workspace(g.Z, g.B, g.H, g.W, g.Ci, g.Co)}, x.options().dtype(at::kByte));
+  check(dgtd_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), mask, dw.data_ptr(), has_b ? db.data_ptr() : nullptr, ws.data_ptr(), g.Z, g.B, g.H,
+                           g.W, g.Ci, g.Co, g.shared ? 1 : 0, stream()), "dgtd_conv3x3_wgrad");
+}
+
+struct Conv3x3Fn : public torch::autograd::Function<Conv3x3Fn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w_, const c10::optional<Tensor>& b_, bool relu) {
+    Tensor x = x_.contiguous(), w = w_.contiguous();
+    on_device(x);
+    TORCH_CHECK(x.dim() == 5 && w.dim() == 5 && x.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16,
+                "dgtd conv3x3 takes bf16 x [Z|1,B,H,W,Ci] and w [Z,Co,3,3,Ci]");
+    const bool has_b = b_.has_value() && b_->defined();
+    ConvGeom g{(int)w.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)w.size(4), (int)w.size(1), x.size(0) == 1 && w.size(0) > 1};
+    Tensor b = has_b ? b_->contiguous() : Tensor();
+    Tensor y = at::empty({g.Z, g.B, g.H, g.W, g.Co}, x.options());
+    check(dgtd_conv3x3_fwd(x.data_ptr(), nullptr, w.data_ptr(), has_b ? b.data_ptr() : nullptr, y.data_ptr(), g.Z, g.B, g.H, g.W, g.Ci, g.Co,
+                           relu ? 1 : 0, g.shared ? 1 : 0, stream()), "dgtd_conv3x3_fwd");
+    ctx->save_for_backward({x, w, relu ? y : Tensor()});
+    ctx->saved_data["has_b"] = has_b;
+    ctx->saved_data["need_dx"] = x_.requires_grad();
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w = saved[1], &ym = saved[2];
+    const bool has_b = ctx->saved_data["has_b"].toBool(), need_dx = ctx->saved_data["need_dx"].toBool();
+    ConvGeom g{(int)w.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)w.size(4), (int)w.size(1), x.size(0) == 1 && w.size(0) > 1};
+    Tensor dy = gr[0].contiguous();
+    Tensor dx = need_dx ? at::empty({g.Z, g.B, g.H, g.W, g.Ci}, x.options()) : Tensor();
+    Tensor dw = at::empty_like(w), db = has_b ? at::empty({g.Z, g.Co}, w.options()) : Tensor();
+    conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db);
+    if (need_dx && g.shared) dx = at::sum(dx, {0}, true);
+    return {dx, dw, db, undefined()};
+  }
+};
+
+// logical form: x [B,Ci,H,W] and w [Co,Ci,3,3] in channels_last memory (= NHWC / OHWI); every tensor handed to autograd is a base
+// tensor in channels_last memory format, so no permute / view nodes surround the kernel
+struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w_, const c10::optional<Tensor>& b_, bool relu) {
+    Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast), w = w_.contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16, "dgtd conv3x3 takes bf16 tensors on the HIP device");
+    const bool has_b = b_.has_value() && b_->defined();
+    ConvGeom g{1, (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)w.size(1), (int)w.size(0), false};
+    Tensor b = has_b ? b_->contiguous() : Tensor();
+    Tensor y = at::empty({g.B, g.Co, g.H, g.W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    check(dgtd_conv3x3_fwd(x.data_ptr(), nullptr, w.data_ptr(), has_b ? b.data_ptr() : nullptr, y.data_ptr(), 1, g.B, g.H, g.W, g.Ci, g.Co,
+                           relu ? 1 : 0, 0, stream()), "dgtd_conv3x3_fwd");
+    ctx->save_for_backward({x, w, relu ? y : Tensor()});
+    ctx->saved_data["has_b"] = has_b;
+    ctx->saved_data["need_dx"] = x_.requires_grad();
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w = saved[1], &ym = saved[2];
+    const bool has_b = ctx->saved_data["has_b"].toBool(), need_dx = ctx->saved_data["need_dx"].toBool();
+    ConvGeom g{1, (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)w.size(1), (int)w.size(0), false};
+    Tensor dy = gr[0].contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dx = need_dx ? at::empty_like(x) : Tensor();
+    Tensor dw = at::empty_like(w), db = has_b ? at::empty({g.Co}, w.options()) : Tensor();
+    conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db);
+    return {dx, dw, db, undefined()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ Hitnet glue: PReLU, CA gate, bilinear
+inline Tensor dense(const Tensor& x) { return x.is_non_overlapping_and_dense() ? x : x.contiguous(); }
+
+struct PReLUFn : public torch::autograd::Function<PReLUFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& a) {
+    Tensor x = dense(x_);
+    TORCH_CHECK(x.is_cuda() && a.numel() == 1, "dgtd prelu: single-slope PReLU on the HIP device");
+    Tensor a32 = f32(a);
+    Tensor y = at::empty_like(x);
+    check(dgtd_prelu_fwd(x.data_ptr(), a32.data_ptr<float>(), y.data_ptr(), x.numel(), code(x), stream()), "dgtd_prelu_fwd");
+    ctx->save_for_backward({x, a32});
+    ctx->saved_data["a_bf16"] = a.scalar_type() == at::kBFloat16;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &a32 = saved[1];
+    Tensor g = gr[0];
+    if (g.scalar_type() != x.scalar_type() || g.strides() != x.strides()) g = at::empty_like(x).copy_(g);
+    Tensor dx = at::empty_like(x);
+    Tensor da = at::zeros({1}, x.options().dtype(at::kFloat));
+    check(dgtd_prelu_bwd(x.data_ptr(), g.data_ptr(), a32.data_ptr<float>(), dx.data_ptr(), da.data_ptr<float>(), x.numel(), code(x), stream()),
+          "dgtd_prelu_bwd");
+    if (ctx->saved_data["a_bf16"].toBool()) da = da.to(at::kBFloat16);
+    return {dx, da};
+  }
+};
+
+struct CAGateFn : public torch::autograd::Function<CAGateFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& res_, const Tensor& x_, const Tensor& w1, const Tensor& w2) {
+    Tensor res = res_.contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor x = (x_.scalar_type() == res.scalar_type() ? x_ : x_.to(res.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(res.is_cuda(), "dgtd ca_gate runs on the HIP device");
+    const int64_t B = res.size(0), C = res.size(1), HW = res.size(2) * res.size(3), R = w1.size(0);
+    Tensor w1f = f32(w1.reshape({R, C})), w2f = f32(w2.reshape({C, R}));
+    Tensor stats = at::zeros({2 * B * C + B * R}, res.options().dtype(at::kFloat));
+    Tensor out = at::empty_like(res);
+    check(dgtd_ca_gate_fwd(res.data_ptr(), x.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), out.data_ptr(), stats.data_ptr<float>(),
+                           (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_fwd");
+    ctx->save_for_backward({res, w1f, w2f, stats});
+    ctx->saved_data["w_bf16"] = w1.scalar_type() == at::kBFloat16;
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &res = saved[0], &w1f = saved[1], &w2f = saved[2], &stats = saved[3];
+    const int64_t B = res.size(0), C = res.size(1), HW = res.size(2) * res.size(3), R = w1f.size(0);
+    Tensor g = (gr[0].scalar_type() == res.scalar_type() ? gr[0] : gr[0].to(res.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dres = at::empty_like(res);
+    Tensor small = at::zeros({2 * R * C + 2 * B * C}, res.options().dtype(at::kFloat));
+    float* sp = small.data_ptr<float>();
+    check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(),
+                           sp, sp + R * C, sp + 2 * R * C, (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_bwd");
+    Tensor dw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1}), dw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});
+    if (ctx->saved_data["w_bf16"].toBool()) { dw1 = dw1.to(at::kBFloat16); dw2 = dw2.to(at::kBFloat16); }
+    return {dres, g, dw1, dw2};
+  }
+};
+
+struct BilinearFn : public torch::autograd::Function<BilinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, int64_t Ho, int64_t Wo, bool align) {
+    Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(x.is_cuda() && x.dim() == 4, "dgtd bilinear_resize takes a 4-D tensor on the HIP device");
+    const int64_t B = x.size(0), C = x.size(1), Hi = x.size(2), Wi = x.size(3);
+    Tensor y = at::empty({B, C, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    check(dgtd_bilinear_fwd(x.data_ptr(), y.data_ptr(), (int)B, (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, align ? 1 : 0, code(x), stream()),
+          "dgtd_bilinear_fwd");
+    ctx->saved_data["geom"] = std::vector<int64_t>{B, C, Hi, Wi, Ho, Wo, align ? 1 : 0, x.scalar_type() == at::kBFloat16 ? 1 : 0};
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    const auto q = ctx->saved_data["geom"].toIntVector();
+    const auto dt = q[7] ? at::kBFloat16 : at::kFloat;
+    Tensor g = (gr[0].scalar_type() == dt ? gr[0] : gr[0].to(dt)).contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dx = at::empty({q[0], q[1], q[2], q[3]}, g.options().memory_format(at::MemoryFormat::ChannelsLast));
+    check(dgtd_bilinear_bwd(g.data_ptr(), dx.data_ptr(), (int)q[0], (int)q[2], (int)q[3], (int)q[4], (int)q[5], (int)q[1], (int)q[6], code(g), stream()),
+          "dgtd_bilinear_bwd");
+    return {dx, undefined(), undefined(), undefined()};
+  }
+};
+
 Tensor layer_norm(const Tensor& x, const Tensor& w, const Tensor& b, double eps) { return LayerNormFn::apply(x, w, b, eps); }
 Tensor sra_attention(const Tensor& q, const Tensor& kv, int64_t heads, double scale) { return SraAttnFn::apply(q, kv, heads, scale); }
 Tensor dwconv_nhwc(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool gelu) { return DwConvFn::apply(x, w, b, gelu); }
@@ -267,6 +427,11 @@ Tensor scale_residual(const Tensor& x, const Tensor& y, const c10::optional<Tens
   return ScaleResidualFn::apply(x, y, s, gamma);
 }
 Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t dt_code) { return LinearFn::apply(x, w, b, dt_code); }
+Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3Fn::apply(x, w, b, relu); }
+Tensor conv3x3_cl(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3ClFn::apply(x, w, b, relu); }
+Tensor prelu(const Tensor& x, const Tensor& a) { return PReLUFn::apply(x, a); }
+Tensor ca_gate(const Tensor& res, const Tensor& x, const Tensor& w1, const Tensor& w2) { return CAGateFn::apply(res, x, w1, w2); }
+Tensor bilinear_resize(const Tensor& x, int64_t oh, int64_t ow, bool align) { return BilinearFn::apply(x, oh, ow, align); }
 
 }  // namespace
 
@@ -276,4 +441,9 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("dwconv_nhwc(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> Tensor", &dwconv_nhwc);
   m.def("scale_residual(Tensor x, Tensor y, Tensor? s, Tensor? gamma) -> Tensor", &scale_residual);
   m.def("linear(Tensor x, Tensor weight, Tensor? bias, int dtype_code) -> Tensor", &linear);
+  m.def("conv3x3(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3);
+  m.def("conv3x3_cl(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3_cl);
+  m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);
+  m.def("ca_gate(Tensor res, Tensor x, Tensor w1, Tensor w2) -> Tensor", &ca_gate);
+  m.def("bilinear_resize(Tensor x, int oh, int ow, bool align) -> Tensor", &bilinear_resize);
 }

@@ -547,7 +547,13 @@ class CAB(nn.Module):
     def forward(self, x):
         act, du = self.body[1], self.CA.conv_du
         if _USE["cab_glue"] and x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and du[0].bias is None and du[2].bias is None:
-            res = self.body[2](ops.prelu(self.body[0](x), act.weight))
+            c0, c1 = self.body[0], self.body[2]
+            w0, w1 = wb(c0)[0], wb(c1)[0]
+            if (_USE["conv3x3"] and c0.bias is None and c1.bias is None and w0.dtype == x.dtype
+                    and ops.conv3x3_ops.supported(x, x.shape[1], x.shape[1], x.shape[2], x.shape[3])):
+                res = ops.conv3x3(ops.prelu(ops.conv3x3(x, w0), act.weight), w1)      # NHWC bf16 MFMA kernels
+            else:
+                res = c1(ops.prelu(c0(x), act.weight))
             return ops.ca_gate(res, x, du[0].weight, du[2].weight)     # gate * res + x in three launches
         return self.CA(self.body(x)) + x
 

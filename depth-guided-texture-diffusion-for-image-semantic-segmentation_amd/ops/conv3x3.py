@@ -10,6 +10,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 
 def supported(x: torch.Tensor, Ci: int, Co: int, H: int, W: int) -> bool:
@@ -68,6 +69,9 @@ def _ohwi(w: torch.Tensor) -> torch.Tensor:
 
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """F.conv2d(x, weight, bias, padding=1) (+ReLU) for a logical [B,C,H,W] tensor; the result is a channels_last view."""
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.conv3x3_cl(x, weight, bias, relu)
     xn = x.permute(0, 2, 3, 1).contiguous().unsqueeze(0)               # NHWC: a view for channels_last inputs
     y = _Conv3x3Fn.apply(xn, _ohwi(weight).unsqueeze(0), bias.unsqueeze(0) if bias is not None else None, relu)
     return y[0].permute(0, 3, 1, 2)
@@ -80,4 +84,7 @@ def conv3x3_stack(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Opti
     b = torch.stack(list(biases)) if biases is not None else None
     if x.ndim == 4:
         x = x.unsqueeze(0)
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.conv3x3(x, w, b, relu)
     return _Conv3x3Fn.apply(x.contiguous(), w, b, relu)

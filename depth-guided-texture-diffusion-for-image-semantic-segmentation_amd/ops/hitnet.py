@@ -8,6 +8,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import _native
 
 
 def _dense(x: torch.Tensor) -> torch.Tensor:
@@ -56,6 +57,9 @@ def prelu(x: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
     """nn.PReLU() with a single shared slope (cod.py:686; applied inside every CAB, cod.py:444-446)."""
     if a.numel() != 1:
         raise L.DgtdError("dgtd prelu implements the single-slope nn.PReLU() the reference constructs (cod.py:686)")
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.prelu(x, a)
     return _PReLUFn.apply(x, a)
 
 
@@ -97,6 +101,9 @@ class _CAGateFn(Function):
 def ca_gate(res: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     """res * sigmoid(conv1x1_w2(relu(conv1x1_w1(avgpool(res))))) + x — CALayer (cod.py:428-431) and the CAB residual (cod.py:451).
     w1 [C/r, C, 1, 1], w2 [C, C/r, 1, 1] are the bias-free conv_du weights (cod.py:421-425)."""
+    nat = _native.ops()
+    if nat is not None and res.is_cuda:
+        return nat.ca_gate(res, x, w1, w2)
     return _CAGateFn.apply(res, x, w1, w2)
 
 
@@ -125,4 +132,7 @@ class _BilinearFn(Function):
 
 def bilinear_resize(x: torch.Tensor, out_h: int, out_w: int, align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size=(out_h, out_w), mode="bilinear", align_corners=...) for a logical [B,C,H,W] map kept channels_last."""
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.bilinear_resize(x, int(out_h), int(out_w), bool(align_corners))
     return _BilinearFn.apply(x, int(out_h), int(out_w), bool(align_corners))
