@@ -150,22 +150,23 @@ constexpr int lds_stride_for(int c) {   // row stride (elements) of a pixel-majo
   return (s % 64 == 0) ? s + 32 : s;
 }
 
-// grid (P pixel splits, ceil(Co/32) output-channel tiles, Z).  Workgroup: 32 output channels x all 9*ceil(CI/32) (tap, 32-channel
-// block) tiles, distributed round-robin over the 4 waves; loops over its share of TH x TW pixel tiles, K = 16 pixels per MFMA.
-// partial [Z][MTt][P][32 co][9][CB*32 ci] fp32 (+ bias partial [Z][MTt][P][32]).
+// grid (P pixel splits, ceil(Co/32) output-channel tiles x NS filter-row groups, Z).  Workgroup: 32 output channels x the
+// (9/NS)*ceil(CI/32) (tap, 32-channel block) tiles of its filter rows, distributed round-robin over the 4 waves; loops over its
+// share of TH x TW pixel tiles, K = 16 pixels per MFMA.  NS = 3 when CI > 32 (more workgroups for the same partial-sum volume).
+// partial [Z][MTt][P][32 co][9][CB*32 ci] fp32 (+ bias partial [Z][MTt][P][32], written by the ky-group 0 workgroups).
 template <int CI, int TH, int TW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                             const bf16_t* __restrict__ mask, float* __restrict__ partial,
                                                             float* __restrict__ partial_b, int B, int H, int W, int Co,
                                                             int tiles_w, int tiles_h, long x_zs, long dy_zs) {
   constexpr int G = CI / 8, CB = (CI + 31) / 32, XS = lds_stride_for(CI), LW = TW + 2, LP = (TH + 2) * LW, NPIX = TH * TW;
-  constexpr int NTN = 9 * CB, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
+  constexpr int NS = CI > 32 ? 3 : 1, NTN = 9 * CB / NS, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* xt = reinterpret_cast<bf16_t*>(smem);          // [LP][XS]
   bf16_t* dt = xt + LP * XS;                             // [NPIX][32]
   __shared__ float bred[8][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int p = blockIdx.x, P = gridDim.x, mt = blockIdx.y, MTt = gridDim.y, z = blockIdx.z;
+  const int p = blockIdx.x, P = gridDim.x, mt = blockIdx.y / NS, kg = blockIdx.y % NS, MTt = gridDim.y / NS, z = blockIdx.z;
   const int ntiles = B * tiles_h * tiles_w;
   f32x16 acc[TPW];
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
       *reinterpret_cast<bf16x8*>(dt + pix * 32 + q * 8) = v;
     }
     __syncthreads();
-    {   // bias gradient: thread (co = tid & 31, slice = tid >> 5) sums every 8th pixel of the dy tile
+    if (kg == 0) {   // bias gradient: thread (co = tid & 31, slice = tid >> 5) sums every 8th pixel of the dy tile
       const int co = tid & 31, sl = tid >> 5;
       float s = 0.f;
       for (int pix = sl; pix < NPIX; pix += 8) s += (float)dt[pix * 32 + co];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
       for (int i = 0; i < TPW; ++i) {
         const int tl = wave + 4 * i;
         if (tl < NTN) {
-          const int tap = tl / CB, cb = tl % CB;
+          const int tap = kg * (9 / NS) + tl / CB, cb = tl % CB;
           const bf16x8 bfr = lds_tr_frag(xt, XS, (r + tap / 3) * LW + c0 + tap % 3, cb * 32, lane);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[i], 0, 0, 0);
         }
@@ -229,14 +230,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
   for (int i = 0; i < TPW; ++i) {
     const int tl = wave + 4 * i;
     if (tl < NTN) {
-      const int tap = tl / CB, cb = tl % CB;
+      const int tap = kg * (9 / NS) + tl / CB, cb = tl % CB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pp[((size_t)mfma_row(r, half) * 9 + tap) * (CB * 32) + cb * 32 + l31] = acc[i][r];
     }
   }
   bred[tid >> 5][tid & 31] = bsum;
   __syncthreads();
-  if (tid < 32) {
+  if (kg == 0 && tid < 32) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += bred[k][tid];
@@ -332,7 +333,7 @@ int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void
   const long plane = (long)B * H * W;
   float* partial = (float*)ws;
   float* partial_b = partial + (size_t)Z * MTt * P * 32 * 9 * (CB * 32);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CI, TH, TW>), dim3(P, MTt, Z), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy,
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), Z), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy,
                      (const bf16_t*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad");
   const long n = (long)Z * Co * 9 * CI;
@@ -345,8 +346,12 @@ int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void
 inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
   const int tw = W >= 32 ? 32 : 16, th = Ci >= 64 ? 4 : 8;
   const long ntiles = (long)B * cdiv(H, th) * cdiv(W, tw);
-  const long want = std::max<long>(1, 1024 / ((long)Z * cdiv(Co, 32)));
-  return (int)std::max<long>(1, std::min<long>(std::min<long>(ntiles, want), 256));
+  const long ygroups = (long)Z * cdiv(Co, 32) * (Ci > 32 ? 3 : 1);
+  const long want = std::max<long>(1, 512 / ygroups);                              // ~2 workgroups per CU
+  // the partial sums written (and re-read by the reduce kernel) should stay below the bytes of the two input maps
+  const long in_bytes = 2L * ((long)Z * B * H * W * (Ci + Co)), part_bytes = (long)Z * cdiv(Co, 32) * 32 * 9 * ((Ci + 31) / 32 * 32) * 4;
+  const long cap = std::max<long>(4, in_bytes / part_bytes);
+  return (int)std::max<long>(1, std::min<long>(std::min<long>(ntiles, want), std::min<long>(cap, 256)));
 }
 
 }  // namespace
