@@ -66,23 +66,4 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16_t* base, int stride, in
   return f;
 }
 
-// Two-stage reductions in ONE launch: every workgroup of a group writes its partial sums, then calls this; it returns true in
-// exactly one of the `n_groups` workgroups that share `counter` - the last one to arrive - which then reduces the partials (all of
-// them are visible to it) in a fixed order.  `counter` must be zero on entry and is left zero (workspaces are zero-filled once by
-// the host and reused).  Must be called by all 256 threads of the workgroup.
-__device__ __forceinline__ bool last_group_done(unsigned* counter, unsigned n_groups) {
-  __shared__ int dgtd_last_flag;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(counter, 1u);
-    dgtd_last_flag = (prev == n_groups - 1);
-    if (prev == n_groups - 1) *counter = 0u;
-  }
-  __syncthreads();
-  const bool last = dgtd_last_flag != 0;
-  if (last) __threadfence();
-  return last;
-}
-
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

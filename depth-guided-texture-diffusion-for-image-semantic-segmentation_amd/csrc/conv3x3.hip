@@ -7,8 +7,8 @@
 //   backward/x   the same kernel on dy with the transposed + spatially flipped kernel (conv3x3_flip_kernel); the ReLU of the
 //                forward is undone while the dy tile is staged (value kept where the saved forward output is > 0)
 //   backward/w   dw[z,co,ky,kx,ci] = sum_{b,h,w} dy[z,b,h,w,co] * x[z|0,b,h+ky-1,w+kx-1,ci]: pixels are the MFMA K dimension; both
-//                operands come from pixel-major LDS tiles through the transposing read (ds_read_b64_tr_b16); the last workgroup of
-//                each output slice reduces the per-workgroup partial sums in a fixed order (same launch) and emits dw and db.
+//                operands come from pixel-major LDS tiles through the transposing read (ds_read_b64_tr_b16), per-workgroup partial
+//                sums are reduced in a fixed order by conv3x3_wgrad_reduce_kernel, which also emits the bias gradient.
 //
 // Roofline: HBM.  Algorithmic bytes per convolution and direction = 2 B * B*H*W * (Ci + Co) (+ the mask map in the backward);
 // arithmetic intensity 9*Ci*Co/(Ci+Co) flop/B = 108 (24->24) .. 432 (96->96), far below the bf16 MFMA ridge (~300 flop/B only
@@ -157,9 +157,8 @@ constexpr int lds_stride_for(int c) {   // row stride (elements) of a pixel-majo
 template <int CI, int TH, int TW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                             const bf16_t* __restrict__ mask, float* __restrict__ partial,
-                                                            float* __restrict__ partial_b, unsigned* __restrict__ counters,
-                                                            bf16_t* __restrict__ dw, bf16_t* __restrict__ db, int B, int H, int W,
-                                                            int Co, int tiles_w, int tiles_h, long x_zs, long dy_zs) {
+                                                            float* __restrict__ partial_b, int B, int H, int W, int Co,
+                                                            int tiles_w, int tiles_h, long x_zs, long dy_zs) {
   constexpr int G = CI / 8, CB = (CI + 31) / 32, XS = lds_stride_for(CI), LW = TW + 2, LP = (TH + 2) * LW, NPIX = TH * TW;
   constexpr int NS = CI > 32 ? 3 : 1, NTN = 9 * CB / NS, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -244,28 +243,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
     for (int k = 0; k < 8; ++k) s += bred[k][tid];
     partial_b[(((size_t)z * MTt + mt) * P + p) * 32 + tid] = s;
   }
-  // second stage in the same launch: the last of the P workgroups of this (z, co tile, filter-row group) sums their partials in a
-  // fixed order and writes dw [Z][Co][9][CI] (and db) in bf16
-  if (!last_group_done(counters + ((size_t)z * MTt + mt) * NS + kg, P)) return;
-  constexpr int CBW = CB * 32, T = 9 / NS;
-  const float* base = partial + (((size_t)z * MTt + mt) * P * 32) * 9 * CBW;
-  const size_t ps = (size_t)32 * 9 * CBW;
-  for (int o = tid; o < 32 * T * CI; o += 256) {
-    const int ci = o % CI, t2 = (o / CI) % T, cl = o / (CI * T);
-    const int co = mt * 32 + cl, tap = kg * T + t2;
-    if (co >= Co) continue;
-    const float* q0 = base + ((size_t)cl * 9 + tap) * CBW + ci;
+}
+
+// dw [Z][Co][9][CI] bf16 and db [Z][Co] bf16 from the partials (fixed summation order)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
+                                                                   bf16_t* __restrict__ dw, bf16_t* __restrict__ db, int Z, int Co,
+                                                                   int CI, int CB, int MTt, int P) {
+  const long n = (long)Z * Co * 9 * CI;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int ci = (int)(i % CI);
+    long r = i / CI;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int co = (int)(r % Co);
+    const long z = r / Co;
+    const int mt = co >> 5, cl = co & 31;
+    const float* pp = partial + (((size_t)z * MTt + mt) * P * 32 + cl) * 9 * (CB * 32) + (size_t)tap * (CB * 32) + ci;
+    const size_t ps = (size_t)32 * 9 * (CB * 32);
     float s0 = 0.f, s1 = 0.f;
     int q = 0;
-    for (; q + 1 < P; q += 2) { s0 += q0[q * ps]; s1 += q0[(q + 1) * ps]; }
-    if (q < P) s0 += q0[q * ps];
-    dw[(((size_t)z * Co + co) * 9 + tap) * CI + ci] = (bf16_t)(s0 + s1);
+    for (; q + 1 < P; q += 2) { s0 += pp[q * ps]; s1 += pp[(q + 1) * ps]; }
+    if (q < P) s0 += pp[q * ps];
+    dw[i] = (bf16_t)(s0 + s1);
   }
-  if (kg == 0 && db && tid < 32 && mt * 32 + tid < Co) {
-    const float* pb = partial_b + (((size_t)z * MTt + mt) * P) * 32 + tid;
-    float sb = 0.f;
-    for (int q = 0; q < P; ++q) sb += pb[(size_t)q * 32];
-    db[(size_t)z * Co + mt * 32 + tid] = (bf16_t)sb;
+  if (db && i < (long)Z * Co) {
+    const int co = (int)(i % Co);
+    const long z = i / Co;
+    const float* pb = partial_b + (((size_t)z * MTt + (co >> 5)) * P) * 32 + (co & 31);
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += pb[(size_t)q * 32];
+    db[i] = (bf16_t)s;
   }
 }
 
@@ -323,14 +331,15 @@ int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void
   static_assert(lds <= 65536, "wgrad tiles exceed 64 KB of LDS");
   const int tiles_w = (int)cdiv(W, TW), tiles_h = (int)cdiv(H, TH), MTt = (int)cdiv(Co, 32);
   const long plane = (long)B * H * W;
-  unsigned* counters = (unsigned*)ws;                      // zero on entry, left zero (include/dgtd.h)
-  float* partial = (float*)((char*)ws + 4096);
+  float* partial = (float*)ws;
   float* partial_b = partial + (size_t)Z * MTt * P * 32 * 9 * (CB * 32);
-  DGTD_REQUIRE((size_t)Z * MTt * 3 * sizeof(unsigned) <= 4096, "conv3x3_wgrad: too many convolutions per launch (Z=%d)", Z);
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), Z), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy,
-                     (const bf16_t*)mask, partial, partial_b, counters, (bf16_t*)dw, (bf16_t*)db, B, H, W, Co, tiles_w, tiles_h,
-                     shared_x ? 0L : plane * CI, plane * Co);
+                     (const bf16_t*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad");
+  const long n = (long)Z * Co * 9 * CI;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, (const float*)partial,
+                     (const float*)partial_b, (bf16_t*)dw, (bf16_t*)db, Z, Co, CI, CB, MTt, P);
+  DGTD_CHECK_LAUNCH("conv3x3_wgrad_reduce");
   return 0;
 }
 
@@ -375,7 +384,7 @@ extern "C" int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci,
 
 extern "C" int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co) {
   const int P = wgrad_splits(Z, B, H, W, Ci, Co), CB = (Ci + 31) / 32, MTt = (int)cdiv(Co, 32);
-  return 4096 + (int64_t)Z * MTt * P * 32 * (9 * CB * 32 + 1) * (int64_t)sizeof(float);
+  return (int64_t)Z * MTt * P * 32 * (9 * CB * 32 + 1) * (int64_t)sizeof(float);
 }
 
 extern "C" int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,

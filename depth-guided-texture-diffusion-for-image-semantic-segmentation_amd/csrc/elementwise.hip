@@ -9,10 +9,7 @@
 
 namespace {
 
-constexpr int EW_MAX_BLOCKS = 256;        // partial rows per column strip (second stage runs inside the same launch)
-constexpr int EW_STRIP = 8;               // 16-byte chunks per workgroup column strip = 128 bytes of every row
-constexpr int EW_MAX_STRIPS = 1024;
-constexpr int EW_COUNTER_BYTES = EW_MAX_STRIPS * 4;
+constexpr int EW_MAX_BLOCKS = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
@@ -42,17 +39,16 @@ __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const T* __rest
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ s,
                                                      const float* __restrict__ gamma, T* __restrict__ dy, float* __restrict__ ws,
-                                                     unsigned* __restrict__ counters, void* __restrict__ out, int out_bf16,
                                                      int64_t rows, int C, int64_t rows_per_sample) {
   typedef typename Vec16<T>::type VT;
   constexpr int V = Vec16<T>::N;
-  __shared__ float red[256 * V];                 // [RG][CVB * V]
+  extern __shared__ float red[];                 // [RG][CVB * V]
   const int CV = C / V;
-  const int CVB = min(CV - (int)blockIdx.y * EW_STRIP, EW_STRIP);   // 16-byte column chunks handled by this workgroup (a 128-byte strip)
-  const int RG = 256 / CVB;                                         // row lanes inside the workgroup
+  const int CVB = min(CV - (int)blockIdx.y * 256, 256);       // chunk-columns handled by this workgroup
+  const int RG = 256 / CVB;                                   // row groups inside the workgroup (CVB is a power of two or <= 256)
   const int tid = threadIdx.x;
   const int cvl = tid % CVB, rg = tid / CVB;
-  const int cv = blockIdx.y * EW_STRIP + cvl;
+  const int cv = blockIdx.y * 256 + cvl;
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -90,26 +86,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
 #pragma unroll
     for (int j = 0; j < V; ++j) red[(rg * CVB + cvl) * V + j] = acc[j];
   __syncthreads();
-  const int ncol = CVB * V, col0 = blockIdx.y * EW_STRIP * V;
-  for (int i = tid; i < ncol; i += 256) {
+  for (int i = tid; i < CVB * V; i += 256) {
     float t = 0.f;
-    for (int k = 0; k < RG; ++k) t += red[k * ncol + i];
-    ws[(size_t)blockIdx.x * C + col0 + i] = t;
+    for (int k = 0; k < RG; ++k) t += red[k * CVB * V + i];
+    ws[(size_t)blockIdx.x * C + (size_t)blockIdx.y * 256 * V + i] = t;
   }
-  // second stage in the same launch: the last workgroup of this column strip sums the gridDim.x partial rows in a fixed order
-  if (!last_group_done(counters + blockIdx.y, gridDim.x)) return;
-  const int nb = gridDim.x, i = tid % ncol, q = tid / ncol, Q = 256 / ncol;   // ncol <= 64: Q >= 4 interleaved partial sums per column
-  float t = 0.f;
-  if (q < Q)
-    for (int k = q; k < nb; k += Q) t += ws[(size_t)k * C + col0 + i];
+}
+
+// ws [nblocks][C] -> out[C]; one workgroup per 64 columns, 4 waves over the rows, fixed summation order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, void* __restrict__ out, int out_bf16, int nblocks, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < C) {
+    const float* p = ws + col;
+    int b = wave;
+    for (; b + 28 < nblocks; b += 32) {
+      const float v0 = p[(size_t)b * C], v1 = p[(size_t)(b + 4) * C], v2 = p[(size_t)(b + 8) * C], v3 = p[(size_t)(b + 12) * C];
+      const float v4 = p[(size_t)(b + 16) * C], v5 = p[(size_t)(b + 20) * C], v6 = p[(size_t)(b + 24) * C], v7 = p[(size_t)(b + 28) * C];
+      s0 += ((v0 + v1) + (v2 + v3));
+      s1 += ((v4 + v5) + (v6 + v7));
+    }
+    for (; b < nblocks; b += 4) s0 += p[(size_t)b * C];
+  }
+  part[wave][lane] = s0 + s1;
   __syncthreads();
-  red[tid] = t;
-  __syncthreads();
-  if (tid < ncol) {
-    float v = 0.f;
-    for (int k = 0; k < Q; ++k) v += red[k * ncol + tid];
-    if (out_bf16) ((bf16_t*)out)[col0 + tid] = (bf16_t)v;
-    else ((float*)out)[col0 + tid] = v;
+  if (wave == 0 && col < C) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (out_bf16) ((bf16_t*)out)[col] = (bf16_t)v;
+    else ((float*)out)[col] = v;
   }
 }
 
@@ -125,17 +131,16 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
                   int C, int64_t rps, hipStream_t st, const char* who, int out_bf16 = 0) {
   if (int rc = check_c<T>(C, who)) return rc;
   constexpr int V = Vec16<T>::N;
-  const int CV = C / V, strips = (int)cdiv(CV, EW_STRIP);
-  DGTD_REQUIRE(strips <= EW_MAX_STRIPS, "%s: C=%d is wider than %d columns", who, C, EW_MAX_STRIPS * EW_STRIP * V);
-  const int rg = 256 / std::min(CV, EW_STRIP);
-  // ~1024 workgroups in total, at least 2 rows per row lane, at most EW_MAX_BLOCKS partial rows for the in-launch second stage
-  const int64_t want = std::max<int64_t>(1, 1024 / strips);
-  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cdiv(rows, (int64_t)rg * 2)), EW_MAX_BLOCKS));
-  unsigned* counters = (unsigned*)ws;
-  float* partial = (float*)((char*)ws + EW_COUNTER_BYTES);
-  hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, strips), dim3(256), 0, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, partial,
-                     counters, out, out_bf16, rows, C, rps);
+  const int CV = C / V, ncb = (int)cdiv(CV, 256);
+  const int cvb0 = std::min(CV, 256), rg = 256 / cvb0;
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, (int64_t)rg * 4), EW_MAX_BLOCKS));
+  const size_t lds = (size_t)256 * V * sizeof(float);
+  hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
+  if (MODE != 2) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, out, out_bf16, gx, C);
+    DGTD_CHECK_LAUNCH(who);
+  }
   return 0;
 }
 
@@ -154,7 +159,7 @@ extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float
   return 0;
 }
 
-extern "C" int64_t dgtd_colsum_workspace(int C) { return EW_COUNTER_BYTES + (int64_t)EW_MAX_BLOCKS * C * sizeof(float); }
+extern "C" int64_t dgtd_colsum_workspace(int C) { return (int64_t)EW_MAX_BLOCKS * C * sizeof(float); }
 
 extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
                                        void* workspace, int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {

@@ -26,14 +26,6 @@ inline void check(int rc, const char* name) { TORCH_CHECK(rc == 0, name, " faile
 inline void on_device(const Tensor& t) { TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "dgtd ops need contiguous tensors on the HIP device"); }
 inline Tensor f32(const Tensor& t) { return t.scalar_type() == at::kFloat ? t.contiguous() : t.to(at::kFloat).contiguous(); }
 inline Tensor undefined() { return Tensor(); }
-// Persistent scratch per thread and stream, zero-filled once: the kernels that take it keep their arrival counters zeroed between
-// calls (include/dgtd.h).  Never freed: a thread_local destructor could run after the HIP runtime has shut down.
-inline Tensor zero_workspace(int64_t nbytes, const at::TensorOptions& opts) {
-  thread_local auto* cache = new std::unordered_map<void*, Tensor>();
-  Tensor& t = (*cache)[stream()];
-  if (!t.defined() || t.numel() < nbytes) t = at::zeros({std::max<int64_t>(nbytes, (int64_t)8 << 20)}, opts.dtype(at::kByte));
-  return t;
-}
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
@@ -179,7 +171,7 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
     const int64_t B = y.size(0), C = y.size(-1), rows = y.numel() / C;
     Tensor dy = at::empty_like(y);
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
-    Tensor ws = has_g ? zero_workspace(dgtd_colsum_workspace((int)C), y.options()) : Tensor();
+    Tensor ws = has_g ? at::empty({dgtd_colsum_workspace((int)C)}, y.options().dtype(at::kByte)) : Tensor();
     check(dgtd_scale_residual_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
                                   dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, has_g ? ws.data_ptr() : nullptr, rows, (int)C,
                                   rows / B, code(y), stream()), "dgtd_scale_residual_bwd");
@@ -193,7 +185,7 @@ Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
   const int64_t rows = x2.size(0), C = x2.size(1);
   if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat).to(out_dt);   // narrower than a 16-byte chunk per lane
   Tensor out = at::empty({C}, x2.options().dtype(out_dt));
-  Tensor ws = zero_workspace(dgtd_colsum_workspace((int)C), x2.options());
+  Tensor ws = at::empty({dgtd_colsum_workspace((int)C)}, x2.options().dtype(at::kByte));
   check(dgtd_colsum(x2.data_ptr(), out.data_ptr(), code(out), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
   return out;
 }
@@ -281,7 +273,7 @@ inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor&
     check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, stream()),
           "dgtd_conv3x3_fwd (input gradient)");
   }
-  Tensor ws = zero_workspace(dgtd_conv3x3_wgrad_workspace(g.Z, g.B, g.H, g.W, g.Ci, g.Co), x.options());
+  Tensor ws = at::empty({dgtd_conv3x3_wgrad_workspace(g.Z, g.B, g.H, g.W, g.Ci, g.Co)}, x.options().dtype(at::kByte));
   check(dgtd_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), mask, dw.data_ptr(), has_b ? db.data_ptr() : nullptr, ws.data_ptr(), g.Z, g.B, g.H,
                            g.W, g.Ci, g.Co, g.shared ? 1 : 0, stream()), "dgtd_conv3x3_wgrad");
 }

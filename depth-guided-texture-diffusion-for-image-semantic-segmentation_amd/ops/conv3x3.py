@@ -55,8 +55,7 @@ class _Conv3x3Fn(Function):
                 dx = dx.sum(0, keepdim=True)
         dw = torch.empty_like(w)
         db = torch.empty(Z, Co, dtype=w.dtype, device=w.device) if has_b else None
-        from .elementwise import _workspace   # persistent, zero-filled once (arrival counters, include/dgtd.h)
-        ws = _workspace(L.load().dgtd_conv3x3_wgrad_workspace(Z, B, H, W, Ci, Co), x.device)
+        ws = torch.empty(L.load().dgtd_conv3x3_wgrad_workspace(Z, B, H, W, Ci, Co), dtype=torch.uint8, device=x.device)
         L.call("dgtd_conv3x3_wgrad", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(dw), L.ptr(db), L.ptr(ws), Z, B, H, W, Ci, Co, int(shared), st,
                algo=("hbm", 2 * ((1 if shared else Z) * B * H * W * Ci + (2 if relu else 1) * dy.numel())),
                key=f"dgtd_conv3x3_wgrad[Z={Z},{H}x{W},{Ci}->{Co}]")

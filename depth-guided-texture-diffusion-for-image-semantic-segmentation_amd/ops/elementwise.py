@@ -14,12 +14,11 @@ SPLITK_WGRAD = os.environ.get("DGTD_SPLITK_WGRAD", "1") != "0"   # A/B switch fo
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Persistent per-device scratch for the two-stage column sums (stream-ordered reuse on the compute stream).  Zero-filled
-    once: the kernels keep their arrival counters (the first 4 KiB) zeroed between calls (include/dgtd.h)."""
+    """Persistent per-device scratch for the two-stage column sums (stream-ordered reuse on the compute stream)."""
     key = (device, torch.cuda.current_stream().cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.zeros(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _WS[key] = t
     return t
 

@@ -85,8 +85,6 @@ int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_
  * gamma fp32 [C] or NULL; row r belongs to sample r / rows_per_sample.                                                */
 int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out,
                             int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st);
-/* Column-sum workspaces hold arrival counters in their first 4 KiB: the buffer must be ZERO-FILLED once by the caller before its
- * first use; the kernels leave the counters zeroed, so the same buffer can be reused by later calls on the same stream.        */
 int64_t dgtd_colsum_workspace(int C);
 /* dy = s*gamma*g (overwritten); dgamma[c] = sum_r s*g*y (overwritten; NULL iff gamma is NULL).  d(out)/dx is the identity. */
 int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy,
@@ -167,8 +165,7 @@ int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void*
 /* wt [Z,Ci,3,3,Co] = w [Z,Co,3,3,Ci] transposed, taps flipped.                                                                  */
 int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s);
 /* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) bf16, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).
- * workspace: dgtd_conv3x3_wgrad_workspace(...) bytes (arrival counters in the first 4 KiB + per-workgroup partial sums, reduced in a
- * fixed order inside the same launch); ZERO-FILLED once by the caller, reusable afterwards like the column-sum workspace.          */
+ * workspace: dgtd_conv3x3_wgrad_workspace(...) bytes of per-workgroup partial sums, reduced in a fixed order.                   */
 int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co);
 int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
                        int H, int W, int Ci, int Co, int shared_x, dgtd_stream s);
