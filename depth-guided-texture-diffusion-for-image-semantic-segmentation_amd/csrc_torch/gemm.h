@@ -49,9 +49,9 @@ inline bool enabled() {
   return on;
 }
 
-inline Ctx& ctx() {
-  thread_local Ctx c;
-  return c;
+inline Ctx& ctx() {   // never destroyed: a thread_local destructor could run after the HIP runtime has shut down
+  thread_local Ctx* c = new Ctx();
+  return *c;
 }
 
 inline bool ok(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS; }
