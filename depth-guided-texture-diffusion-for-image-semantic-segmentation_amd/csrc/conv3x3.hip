@@ -87,16 +87,33 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
     wok[nt] = co < Co;
     wrow[nt] = wz + (size_t)(wok[nt] ? co : 0) * 9 * CI;
   }
+  // The kernel fragments come from global memory (L2-resident, shared by every workgroup); with one wave per SIMD nothing else
+  // hides their latency, so they are fetched WD steps ahead of the MFMAs that consume them (ring of WD x NT fragments).
+  constexpr int WD = NSTEP < 8 ? NSTEP : 8;
+  auto wfrag = [&](int j, int nt) -> bf16x8 {
+    const int f0 = 2 * j, f1 = (2 * j + 1 < NF) ? 2 * j + 1 : 2 * j;
+    const int tap0 = f0 / G, g0 = f0 % G, tap1 = f1 / G, g1 = f1 % G;
+    const int woff = half ? tap1 * CI + g1 * 8 : tap0 * CI + g0 * 8;
+    const bool valid = half ? (2 * j + 1 < NF) : true;
+    return (valid && wok[nt]) ? *reinterpret_cast<const bf16x8*>(wrow[nt] + woff) : zero8();
+  };
+  bf16x8 wq[WD][NT];
+#pragma unroll
+  for (int j = 0; j < WD; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wq[j][nt] = wfrag(j, nt);
 #pragma unroll
   for (int j = 0; j < NSTEP; ++j) {
     const int f0 = 2 * j, f1 = (2 * j + 1 < NF) ? 2 * j + 1 : 2 * j;
     const int tap0 = f0 / G, g0 = f0 % G, tap1 = f1 / G, g1 = f1 % G;
     const int aoff = half ? g1 * LP + (tap1 / 3) * LW + tap1 % 3 : g0 * LP + (tap0 / 3) * LW + tap0 % 3;
-    const int woff = half ? tap1 * CI + g1 * 8 : tap0 * CI + g0 * 8;
-    const bool valid = half ? (2 * j + 1 < NF) : true;
     bf16x8 wf[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wf[nt] = (valid && wok[nt]) ? *reinterpret_cast<const bf16x8*>(wrow[nt] + woff) : zero8();
+    for (int nt = 0; nt < NT; ++nt) wf[nt] = wq[j % WD][nt];
+    if (j + WD < NSTEP) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wq[j % WD][nt] = wfrag(j + WD, nt);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const bf16x8 xf = tile[basepix[mt] + aoff];
@@ -180,30 +197,50 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
       *reinterpret_cast<bf16x8*>(xt + pix * XS + CI + g * 8) = zero8();
     }
   }
-  for (int t = p; t < ntiles; t += P) {
+  // The next pixel tile is fetched into registers while the MFMAs of the current one run (one workgroup per CU: nothing else
+  // would hide the global-load latency), then moved to LDS between two barriers.
+  constexpr int NX = (LP * G + 255) / 256, ND = (NPIX * 4 + 255) / 256;
+  bf16x8 xr[NX], dr[ND];
+  auto fetch = [&](int t) {
     const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, b = t / (tiles_w * tiles_h);
     const int h0 = th * TH, w0 = tw * TW;
     const size_t img = (size_t)b * H * W;
     const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
     const bf16_t* db = dy + (size_t)z * dy_zs + img * Co;
     const bf16_t* mb = mask ? mask + (size_t)z * dy_zs + img * Co : nullptr;
-    __syncthreads();   // previous tile fully consumed
-    for (int c = tid; c < LP * G; c += 256) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int c = tid + i * 256;
       const int pix = c / G, g = c % G;
       const int pr = pix / LW, pc = pix % LW;
       const int h = h0 - 1 + pr, ww = w0 - 1 + pc;
-      bf16x8 v = zero8();
-      if (h >= 0 && h < H && ww >= 0 && ww < W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)h * W + ww) * CI + g * 8);
-      *reinterpret_cast<bf16x8*>(xt + pix * XS + g * 8) = v;
+      xr[i] = zero8();
+      if (c < LP * G && h >= 0 && h < H && ww >= 0 && ww < W) xr[i] = *reinterpret_cast<const bf16x8*>(xb + ((size_t)h * W + ww) * CI + g * 8);
     }
-    for (int c = tid; c < NPIX * 4; c += 256) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int c = tid + i * 256;
       const int pix = c >> 2, q = c & 3;
       const int h = h0 + pix / TW, ww = w0 + pix % TW, co = mt * 32 + q * 8;
-      bf16x8 v = zero8();
-      if (h < H && ww < W && co < Co) v = load_masked(db, mb, ((size_t)h * W + ww) * Co + co);
-      *reinterpret_cast<bf16x8*>(dt + pix * 32 + q * 8) = v;
+      dr[i] = zero8();
+      if (c < NPIX * 4 && h < H && ww < W && co < Co) dr[i] = load_masked(db, mb, ((size_t)h * W + ww) * Co + co);
+    }
+  };
+  if (p < ntiles) fetch(p);
+  for (int t = p; t < ntiles; t += P) {
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int c = tid + i * 256;
+      if (c < LP * G) *reinterpret_cast<bf16x8*>(xt + (c / G) * XS + (c % G) * 8) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int c = tid + i * 256;
+      if (c < NPIX * 4) *reinterpret_cast<bf16x8*>(dt + (c >> 2) * 32 + (c & 3) * 8) = dr[i];
     }
     __syncthreads();
+    if (t + P < ntiles) fetch(t + P);
     if (kg == 0) {   // bias gradient: thread (co = tid & 31, slice = tid >> 5) sums every 8th pixel of the dy tile
       const int co = tid & 31, sl = tid >> 5;
       float s = 0.f;
@@ -350,7 +387,7 @@ inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
   const long want = std::max<long>(1, 512 / ygroups);                              // ~2 workgroups per CU
   // the partial sums written (and re-read by the reduce kernel) should stay below the bytes of the two input maps
   const long in_bytes = 2L * ((long)Z * B * H * W * (Ci + Co)), part_bytes = (long)Z * cdiv(Co, 32) * 32 * 9 * ((Ci + 31) / 32 * 32) * 4;
-  const long cap = std::max<long>(4, in_bytes / part_bytes);
+  const long cap = std::max<long>(std::max<long>(4, in_bytes / part_bytes), (16L << 20) / part_bytes);   // small maps: up to 16 MB of partials
   return (int)std::max<long>(1, std::min<long>(std::min<long>(ntiles, want), std::min<long>(cap, 256)));
 }
 
