@@ -40,23 +40,47 @@ __device__ __forceinline__ bf16x8 load_masked(const bf16_t* __restrict__ src, co
 // Workgroup = 4 waves; tile = TWX columns x TH = 4*MT*(32/TWX) rows of output pixels; wave w owns MT m-tiles of 32 pixels
 // ((32/TWX) rows x TWX columns each).  The (TH+2) x (TWX+2) input halo tile is staged in LDS as [channel group of 8][pixel]
 // (16-byte elements): the MFMA B fragment of lane (pixel, k-half) is one conflict-free ds_read_b128.
-// K is the flattened (tap, channel group) index f in [0, 9*CI/8); MFMA step j covers f = 2j (lanes 0-31) and 2j+1 (lanes 32-63).
-// A = kernel rows (co), read from global/L2 (OHWI: 8 channels of one tap are 16 contiguous bytes), D[co][pixel].
+// K runs tap by tap; within a tap an MFMA step covers channel groups 2j (lanes 0-31) and 2j+1 (lanes 32-63).
+// A = kernel rows (co): the [Co][CI] slice of each tap is copied to LDS with coalesced loads (fetched one or two taps ahead into
+// registers) - reading the fragments straight from global memory costs one cache line per lane and was the bottleneck.  D[co][pixel].
 template <int CI, int NT, int MT, int TWX>
 __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ mask,
                                                           const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
                                                           bf16_t* __restrict__ y, int H, int W, int Co, int relu, int tiles_w,
                                                           long x_zs, long w_zs, long y_zs) {
   constexpr int G = CI / 8, RW = 32 / TWX, TH = 4 * MT * RW, LW = TWX + 2, LP = (TH + 2) * LW;
-  constexpr int NF = 9 * G, NSTEP = (NF + 1) / 2;
+  constexpr int COP = NT * 32, GP = G | 1, WSZ = COP * GP, NWR = (COP * G + 255) / 256;
+  constexpr int WB = ((size_t)G * LP + 2 * WSZ) * 16 <= 65536 ? 2 : 1;   // double-buffer the kernel slices when LDS allows
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* tile = reinterpret_cast<bf16x8*>(smem);   // [G][LP]
+  bf16x8* wbuf = tile + G * LP;                      // [WB][COP][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w, b = blockIdx.y, z = blockIdx.z;
   const int h0 = th * TH, w0 = tw * TWX;
   const size_t img = (size_t)b * H * W;
   const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
   const bf16_t* mb = mask ? mask + (size_t)z * x_zs + img * CI : nullptr;
+  const bf16_t* wz = w + (size_t)z * w_zs;
+
+  // kernel slice of one tap, [co][GP] 16-byte chunks in LDS (GP odd: the A-fragment reads of 16 consecutive lanes hit 16 different
+  // 16-byte bank groups); fetched from global with channel-group-fastest indexing (CI*2 contiguous bytes per output channel)
+  bf16x8 wr[NWR];
+  auto wfetch = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int c = tid + i * 256;
+      const int co = c / G, g = c % G;
+      wr[i] = (c < COP * G && co < Co) ? *reinterpret_cast<const bf16x8*>(wz + ((size_t)co * 9 + tap) * CI + g * 8) : zero8();
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int c = tid + i * 256;
+      if (c < COP * G) wbuf[buf * WSZ + (c / G) * GP + c % G] = wr[i];
+    }
+  };
+  wfetch(0);
   for (int c = tid; c < LP * G; c += 256) {
     const int pix = c / G, g = c % G;
     const int pr = pix / LW, pc = pix % LW;
@@ -65,7 +89,10 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
     if (h >= 0 && h < H && ww >= 0 && ww < W) v = load_masked(xb, mb, ((size_t)h * W + ww) * CI + g * 8);
     tile[g * LP + pix] = v;
   }
-  __syncthreads();
+  if (WB == 2) {
+    wstore(0);
+    wfetch(1);
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -78,47 +105,33 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
   int basepix[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) basepix[mt] = ((wave * MT + mt) * RW + pr) * LW + pc;
-  const bf16_t* wz = w + (size_t)z * w_zs;
-  const bf16_t* wrow[NT];
-  bool wok[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = nt * 32 + l31;
-    wok[nt] = co < Co;
-    wrow[nt] = wz + (size_t)(wok[nt] ? co : 0) * 9 * CI;
-  }
-  // The kernel fragments come from global memory (L2-resident, shared by every workgroup); with one wave per SIMD nothing else
-  // hides their latency, so they are fetched WD steps ahead of the MFMAs that consume them (ring of WD x NT fragments).
-  constexpr int WD = NSTEP < 8 ? NSTEP : 8;
-  auto wfrag = [&](int j, int nt) -> bf16x8 {
-    const int f0 = 2 * j, f1 = (2 * j + 1 < NF) ? 2 * j + 1 : 2 * j;
-    const int tap0 = f0 / G, g0 = f0 % G, tap1 = f1 / G, g1 = f1 % G;
-    const int woff = half ? tap1 * CI + g1 * 8 : tap0 * CI + g0 * 8;
-    const bool valid = half ? (2 * j + 1 < NF) : true;
-    return (valid && wok[nt]) ? *reinterpret_cast<const bf16x8*>(wrow[nt] + woff) : zero8();
-  };
-  bf16x8 wq[WD][NT];
-#pragma unroll
-  for (int j = 0; j < WD; ++j)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wq[j][nt] = wfrag(j, nt);
-#pragma unroll
-  for (int j = 0; j < NSTEP; ++j) {
-    const int f0 = 2 * j, f1 = (2 * j + 1 < NF) ? 2 * j + 1 : 2 * j;
-    const int tap0 = f0 / G, g0 = f0 % G, tap1 = f1 / G, g1 = f1 % G;
-    const int aoff = half ? g1 * LP + (tap1 / 3) * LW + tap1 % 3 : g0 * LP + (tap0 / 3) * LW + tap0 % 3;
-    bf16x8 wf[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wf[nt] = wq[j % WD][nt];
-    if (j + WD < NSTEP) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wq[j % WD][nt] = wfrag(j + WD, nt);
+  for (int tap = 0; tap < 9; ++tap) {
+    if (WB == 2) {
+      __syncthreads();                            // slice `tap` (and at tap 0 the input tile) is in LDS; everyone is done with tap-1
+      if (tap + 1 < 9) wstore((tap + 1) & 1);
+      if (tap + 2 < 9) wfetch(tap + 2);
+    } else {
+      if (tap > 0) __syncthreads();               // everyone is done reading slice tap-1
+      wstore(0);
+      __syncthreads();
+      if (tap + 1 < 9) wfetch(tap + 1);
     }
+    const bf16x8* wb = wbuf + (WB == 2 ? (tap & 1) * WSZ : 0);
+    const int tapoff = (tap / 3) * LW + tap % 3;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const bf16x8 xf = tile[basepix[mt] + aoff];
+    for (int js = 0; js < (G + 1) / 2; ++js) {
+      const bool valid = 2 * js + 1 < G || !half;                    // odd G: the upper half of the last step is empty
+      const int g = valid ? 2 * js + half : 2 * js;
+      bf16x8 wf[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = valid ? wb[(nt * 32 + l31) * GP + g] : zero8();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 xf = tile[g * LP + basepix[mt] + tapoff];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+      }
     }
   }
 
@@ -333,9 +346,9 @@ inline FwdGeom fwd_geom(int Z, int B, int H, int W, int Ci) {
 template <int CI, int NT, int MT, int TWX>
 int launch_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co, int relu,
                int shared_x, hipStream_t st) {
-  constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2);
-  constexpr size_t lds = (size_t)(CI / 8) * LP * 16;
-  static_assert(lds <= 65536, "halo tile exceeds 64 KB of LDS");
+  constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2), G = CI / 8, WSZ = NT * 32 * (G | 1);
+  constexpr size_t lds = ((size_t)G * LP + ((((size_t)G * LP + 2 * WSZ) * 16 <= 65536) ? 2 : 1) * WSZ) * 16;
+  static_assert(lds <= 65536, "halo tile + kernel slices exceed 64 KB of LDS");
   const int tiles_w = (int)cdiv(W, TWX), tiles_h = (int)cdiv(H, TH);
   const long plane = (long)B * H * W;
   hipLaunchKernelGGL((conv3x3_fwd_kernel<CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z), dim3(256), lds, st, (const bf16_t*)x,
