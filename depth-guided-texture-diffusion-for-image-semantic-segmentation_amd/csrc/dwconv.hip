@@ -25,10 +25,8 @@ static bool use_tiled() {
 
 namespace {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_fast(x); }        // common.h: erfc by A&S 7.1.26, |err| <= 1.5e-7
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_fast(x); }
 
 // MODE 0: y = conv(x) + bias          MODE 1: y = gelu(conv(x) + bias)
 // MODE 2: y = aux * gelu'(conv(x) + bias)   (aux = upstream gradient; recomputes the pre-activation)

@@ -14,10 +14,8 @@ namespace {
 
 constexpr int TY = 4, TXW = 16, TXS = 8;   // TXS = strip of outputs a lane computes at a time
 
-__device__ __forceinline__ float gelu_t(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_t(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_t(float x) { return gelu_fast(x); }        // common.h: erfc by A&S 7.1.26, |err| <= 1.5e-7
+__device__ __forceinline__ float gelu_grad_t(float x) { return gelu_grad_fast(x); }
 
 template <typename T> struct Pair2;
 template <> struct Pair2<float> { typedef float type __attribute__((ext_vector_type(2))); };
