@@ -288,7 +288,7 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_fwd: bad dtype %d", (int)dt);
-  // measured (profiles/r01_dwconv_device_times.txt): the LDS-tiled kernel wins 1.6-1.8x for 7x7 (49-tap halo reuse); for 3x3 the direct
+  // measured (profiles/r01_ops_device_times.txt): the LDS-tiled kernel wins 1.6-1.8x for 7x7 (49-tap halo reuse); for 3x3 the direct
   // kernel with 16-byte loads is as fast or faster
   if (K == 7 && C % 128 == 0 && use_tiled()) return dgtd_dwconv_tiled_fwd(x, w_t, bias, aux, y, B, H, W, C, K, mode, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
