@@ -12,6 +12,7 @@ oracle on a bounded sample (cpu_baseline).
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -171,9 +172,24 @@ def main():
                             "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": e["calls"] / args.profile_steps,
                             "avg_us": round(1e3 * e["ms"] / e["calls"], 2), "ms_per_step": round(e["ms"] / args.profile_steps, 3),
                             "traffic": None})
+        # HBM bytes per launch measured offline with rocprofv3 PMC passes of the same kernels at the same shapes (tools/pmc_run.sh:
+        # FETCH_SIZE x2 + WRITE_SIZE in separate runs, MI355X_MICROARCH.md); null where no pass exists for that shape
+        pmc = {}
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_by_bench_key.json"))):
+            try:
+                pmc.update(json.load(open(f)))
+            except (OSError, ValueError):
+                pass
+        for k, e in zip(kernels, [summ[k_["kernel"]] for k_ in kernels]):
+            if k["bound"] == "hbm":
+                k["algorithmic_bytes"] = round(e["amount"] / e["calls"])
+            k["traffic"] = pmc.get(k["kernel"])
         kernels.sort(key=lambda k: -k["ms_per_step"])
         if kernels:
             roofline = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE)"
+            if "algorithmic_bytes" in kernels[0]:
+                roofline["algorithmic_bytes"] = kernels[0]["algorithmic_bytes"]
             roofline["kernel"] = kernels[0]["kernel"]
             roofline["avg_us"] = kernels[0]["avg_us"]
     if world > 1:

@@ -259,7 +259,9 @@ int fwd_launch(const void* x, const float* wt, const float* bias, const void* au
 // columns = B * ceil(W/TX) strip columns per channel block; split each column into `ysplit` row ranges until ~1024 workgroups exist
 static int bww_ysplit(int B, int H, int W, int C, int TX, int K) {
   const int64_t cols = (int64_t)B * cdiv(W, TX) * (C / 128);
-  const int64_t target = K == 3 ? 4096 : 1024;   // workgroups are K waves: keep ~8-12k waves in flight
+  static const int64_t t3 = getenv("DGTD_BWW_TARGET_K3") ? atol(getenv("DGTD_BWW_TARGET_K3")) : 4096;
+  static const int64_t t7 = getenv("DGTD_BWW_TARGET_K7") ? atol(getenv("DGTD_BWW_TARGET_K7")) : 1024;
+  const int64_t target = K == 3 ? t3 : t7;       // workgroups are K waves: keep ~8-12k waves in flight
   int ys = 1;
   while (ys < H && cols * ys < target && (H / (ys * 2)) >= 4) ys *= 2;
   return ys;
