@@ -35,6 +35,9 @@ SIGNATURES = {
     "dgtd_colsum_workspace": (_i64, [_i]),
     "dgtd_scale_residual_bwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _vp, _i64, _i, _i64, _i, _vp]),
     "dgtd_colsum": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "dgtd_colsum2_workspace": (_i64, [_i]),
+    "dgtd_scale_residual_bias_bwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
+    "dgtd_gelu_bias_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
     "dgtd_seg_loss_workspace": (_i64, [_i, _i]),
     "dgtd_seg_loss_fwd": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "dgtd_seg_loss_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),

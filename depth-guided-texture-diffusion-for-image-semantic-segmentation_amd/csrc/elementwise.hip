@@ -144,6 +144,116 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
   return 0;
 }
 
+
+// Two column sums in one pass, for the backward of a Linear fused with its consumer (the bias gradient of the Linear is the column
+// sum of the gradient this kernel produces anyway):
+//   MODE 3 (residual epilogue):  dy = s*gamma*g,  A = sum_r s*g*y (dgamma, only with gamma),  Bsum = sum_r dy   (bias gradient)
+//   MODE 4 (GELU):               dy = g * gelu'(y)  (y = pre-activation),                     Bsum = sum_r dy
+// ws [nblocks][2C] = { A | Bsum } per workgroup, reduced by colsum2_reduce_kernel.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ s,
+                                                      const float* __restrict__ gamma, T* __restrict__ dy, float* __restrict__ ws,
+                                                      int64_t rows, int C, int64_t rows_per_sample) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ float red[];                 // [RG][CVB * V]
+  const int CV = C / V;
+  const int CVB = min(CV - (int)blockIdx.y * 256, 256);
+  const int RG = 256 / CVB;
+  const int tid = threadIdx.x;
+  const int cvl = tid % CVB, rg = tid / CVB;
+  const int cv = blockIdx.y * 256 + cvl;
+  float accA[V], accB[V], gm[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; gm[j] = (MODE == 3 && gamma) ? gamma[cv * V + j] : 1.f; }
+  const bool need_y = MODE == 4 || gamma != nullptr;
+  if (rg < RG) {
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < rows; r += (int64_t)gridDim.x * RG) {
+      const size_t off = (size_t)r * C + (size_t)cv * V;
+      const VT gv = *reinterpret_cast<const VT*>(g + off);
+      VT yv = gv, o;
+      if (need_y) yv = *reinterpret_cast<const VT*>(y + off);
+      if (MODE == 3) {
+        const float sb = s ? s[r / rows_per_sample] : 1.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float gg = sb * (float)gv[j];
+          accA[j] += gg * (float)yv[j];
+          const float d = gg * gm[j];
+          accB[j] += d;
+          o[j] = (T)d;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float d = (float)gv[j] * gelu_grad_fast((float)yv[j]);
+          accB[j] += d;
+          o[j] = (T)d;
+        }
+      }
+      *reinterpret_cast<VT*>(dy + off) = o;
+    }
+  }
+  float* wrow = ws + (size_t)blockIdx.x * 2 * C + (size_t)blockIdx.y * 256 * V;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0 && !(MODE == 3 && gamma)) continue;      // uniform
+    __syncthreads();
+    if (rg < RG)
+#pragma unroll
+      for (int j = 0; j < V; ++j) red[(rg * CVB + cvl) * V + j] = pass == 0 ? accA[j] : accB[j];
+    __syncthreads();
+    for (int i = tid; i < CVB * V; i += 256) {
+      float t = 0.f;
+      for (int k = 0; k < RG; ++k) t += red[k * CVB * V + i];
+      wrow[pass * C + i] = t;
+    }
+  }
+}
+
+// ws [nblocks][2C] -> outA[C] fp32 (columns < C; skipped when outA is NULL) and outB[C] (fp32 or bf16); fixed summation order
+__global__ __launch_bounds__(256) void colsum2_reduce_kernel(const float* __restrict__ ws, float* __restrict__ outA, void* __restrict__ outB,
+                                                             int outB_bf16, int nblocks, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;              // over 2C columns
+  const bool live = col < 2 * C && (col >= C || outA != nullptr);
+  float s0 = 0.f, s1 = 0.f;
+  if (live) {
+    const float* p = ws + col;
+    int b = wave;
+    for (; b + 12 < nblocks; b += 16) {
+      s0 += p[(size_t)b * 2 * C] + p[(size_t)(b + 4) * 2 * C];
+      s1 += p[(size_t)(b + 8) * 2 * C] + p[(size_t)(b + 12) * 2 * C];
+    }
+    for (; b < nblocks; b += 4) s0 += p[(size_t)b * 2 * C];
+  }
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && live) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (col < C) outA[col] = v;
+    else if (outB_bf16) ((bf16_t*)outB)[col - C] = (bf16_t)v;
+    else ((float*)outB)[col - C] = v;
+  }
+}
+
+template <typename T, int MODE>
+int colsum2_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* outA, void* outB, int outB_bf16,
+                   void* ws, int64_t rows, int C, int64_t rps, hipStream_t st, const char* who) {
+  if (int rc = check_c<T>(C, who)) return rc;
+  constexpr int V = Vec16<T>::N;
+  const int CV = C / V, ncb = (int)cdiv(CV, 256);
+  const int cvb0 = std::min(CV, 256), rg = 256 / cvb0;
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, (int64_t)rg * 4), EW_MAX_BLOCKS));
+  const size_t lds = (size_t)256 * V * sizeof(float);
+  hipLaunchKernelGGL((colsum2_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
+  DGTD_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(colsum2_reduce_kernel, dim3((int)cdiv(2 * C, 64)), dim3(256), 0, st, (const float*)ws, outA, outB, outB_bf16, gx, C);
+  DGTD_CHECK_LAUNCH(who);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out, int64_t rows,
@@ -180,4 +290,30 @@ extern "C" int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* wo
   if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
   if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
   DGTD_FAIL(2, "colsum: bad dtype %d", (int)dt);
+}
+
+extern "C" int64_t dgtd_colsum2_workspace(int C) { return (int64_t)EW_MAX_BLOCKS * 2 * C * sizeof(float); }
+
+extern "C" int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
+                                            void* dbias, dgtd_dtype bias_dt, void* workspace, int64_t rows, int C,
+                                            int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0 && dbias, "scale_residual_bias_bwd: bad sizes");
+  DGTD_REQUIRE((gamma == nullptr) == (dgamma == nullptr), "scale_residual_bias_bwd: gamma and dgamma go together");
+  DGTD_REQUIRE(bias_dt == DGTD_F32 || bias_dt == DGTD_BF16, "scale_residual_bias_bwd: bad bias dtype %d", (int)bias_dt);
+  hipStream_t h = (hipStream_t)st;
+  const int ob = bias_dt == DGTD_BF16;
+  if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 3>(g, y, s, gamma, dy, dgamma, dbias, ob, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd");
+  if (dt == DGTD_F32) return colsum2_launch<float, 3>(g, y, s, gamma, dy, dgamma, dbias, ob, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd");
+  DGTD_FAIL(2, "scale_residual_bias_bwd: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_gelu_bias_bwd(const void* g, const void* pre, void* dpre, void* dbias, dgtd_dtype bias_dt, void* workspace,
+                                  int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && dbias, "gelu_bias_bwd: bad sizes");
+  DGTD_REQUIRE(bias_dt == DGTD_F32 || bias_dt == DGTD_BF16, "gelu_bias_bwd: bad bias dtype %d", (int)bias_dt);
+  hipStream_t h = (hipStream_t)st;
+  const int ob = bias_dt == DGTD_BF16;
+  if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 4>(g, pre, nullptr, nullptr, dpre, nullptr, dbias, ob, workspace, rows, C, 1, h, "gelu_bias_bwd");
+  if (dt == DGTD_F32) return colsum2_launch<float, 4>(g, pre, nullptr, nullptr, dpre, nullptr, dbias, ob, workspace, rows, C, 1, h, "gelu_bias_bwd");
+  DGTD_FAIL(2, "gelu_bias_bwd: bad dtype %d", (int)dt);
 }

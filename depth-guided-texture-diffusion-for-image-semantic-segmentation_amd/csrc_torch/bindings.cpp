@@ -190,28 +190,71 @@ Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
   return out;
 }
 
+// GEMM helpers shared by the Linear nodes: bf16 goes to hipBLASLt with cached plans (gemm.h), anything else to ATen.
+inline Tensor gemm_fwd(const Tensor& x2, const Tensor& wc, const Tensor& bc, Tensor o2 = Tensor()) {   // [M,K] x [N,K]^T (+ bias[N]) -> [M,N]
+  const int64_t M = x2.size(0), K = x2.size(1), N = wc.size(0);
+  if (!o2.defined()) o2 = at::empty({M, N}, x2.options());
+  const bool direct = x2.scalar_type() == at::kBFloat16 && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
+                      dgemm::matmul_bf16(x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), bc.defined() ? bc.data_ptr() : nullptr, M, N, K, false,
+                                         true, 1, 0, 0, 0, x2.options(), (hipStream_t)stream());
+  if (!direct) {
+    if (bc.defined()) at::addmm_out(o2, bc, x2, wc.t());
+    else at::mm_out(o2, x2, wc.t());
+  }
+  return o2;
+}
+inline Tensor gemm_dx(const Tensor& dy2, const Tensor& wc) {                              // [M,N] x [N,K] -> [M,K]
+  const int64_t M = dy2.size(0), N = wc.size(0), K = wc.size(1);
+  Tensor dx2 = at::empty({M, K}, dy2.options());
+  const bool bf = dy2.scalar_type() == at::kBFloat16 && wc.is_contiguous() && M > 0;
+  if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, M, K, N, false, false, 1, 0, 0, 0, dy2.options(),
+                                 (hipStream_t)stream())))
+    at::mm_out(dx2, dy2, wc);
+  return dx2;
+}
+// dW = dY^T X; long token dimensions are split into S batches (library batched GEMM) and summed in fp32: the plain GEMM has only a
+// few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
+inline Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                              // [M,N]^T x [M,K] -> [N,K]
+  const int64_t M = dy2.size(0), N = dy2.size(1), K = x2.size(1);
+  const bool bf = dy2.scalar_type() == at::kBFloat16 && x2.is_contiguous() && M > 0;
+  hipStream_t st = (hipStream_t)stream();
+  const int64_t S = std::min<int64_t>(32, M / 1024);
+  if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
+    Tensor part = at::empty({S, N, K}, dy2.options());
+    if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, N, K, M / S, true, false, (int)S, (M / S) * N,
+                                   (M / S) * K, N * K, dy2.options(), st)))
+      at::bmm_out(part, dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
+    return at::sum(part, {0});   // bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
+  }
+  Tensor dw = at::empty({N, K}, dy2.options());
+  if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, N, K, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
+    at::mm_out(dw, dy2.t(), x2);
+  return dw;
+}
+inline Tensor as_rows(const Tensor& t, at::ScalarType dt) {          // [..., C] -> contiguous [rows, C] in the compute dtype
+  Tensor t2 = t.reshape({-1, t.size(-1)});
+  if (t2.scalar_type() != dt) t2 = t2.to(dt);
+  return t2.contiguous();
+}
+inline std::vector<int64_t> with_last(const Tensor& x, int64_t n) {
+  std::vector<int64_t> sh(x.sizes().begin(), x.sizes().end());
+  sh.back() = n;
+  return sh;
+}
+
 struct LinearFn : public torch::autograd::Function<LinearFn> {
   // compute dtype `dt` is decided by the caller (autocast policy lives in Python)
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b_, int64_t dt_code) {
     const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
     const bool has_b = b_.has_value() && b_->defined();
-    Tensor x2 = x.reshape({-1, x.size(-1)});
-    if (x2.scalar_type() != dt) x2 = x2.to(dt);
+    Tensor x2 = as_rows(x, dt);
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
-    std::vector<int64_t> oshape(x.sizes().begin(), x.sizes().end());
-    oshape.back() = w.size(0);
-    Tensor out = at::empty(oshape, x.options().dtype(dt));
-    Tensor o2 = out.view({-1, w.size(0)});
     Tensor bc;
     if (has_b) bc = b_->scalar_type() == dt ? b_->contiguous() : b_->to(dt);
-    const int64_t M = x2.size(0), K = x2.size(1), N = w.size(0);
-    const bool direct = dt == at::kBFloat16 && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
-                        dgemm::matmul_bf16(x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), has_b ? bc.data_ptr() : nullptr, M, N, K, false, true,
-                                           1, 0, 0, 0, x2.options(), (hipStream_t)stream());
-    if (!direct) {
-      if (has_b) at::addmm_out(o2, bc, x2, wc.t());
-      else at::mm_out(o2, x2, wc.t());
-    }
+    // the output is allocated in its final shape and the GEMM writes into a 2-D alias of it: what autograd sees is a base tensor
+    // (a view created inside a Function may not be modified in place, e.g. by nn.ReLU(inplace=True))
+    Tensor out = at::empty(with_last(x, w.size(0)), x2.options());
+    gemm_fwd(x2, wc, bc, out.view({-1, w.size(0)}));
     ctx->save_for_backward({x2, wc});
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_bf16"] = w.scalar_type() == at::kBFloat16;
@@ -222,41 +265,101 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
   static variable_list backward(AutogradContext* ctx, variable_list g) {
     auto saved = ctx->get_saved_variables();
     const Tensor &x2 = saved[0], &wc = saved[1];
-    Tensor dy2 = g[0].reshape({-1, g[0].size(-1)});
-    if (dy2.scalar_type() != x2.scalar_type()) dy2 = dy2.to(x2.scalar_type());
-    dy2 = dy2.contiguous();
+    Tensor dy2 = as_rows(g[0], x2.scalar_type());
     Tensor dx;
-    const int64_t Mr = dy2.size(0), Nw = wc.size(0), Kw = wc.size(1);
-    const bool bf = dy2.scalar_type() == at::kBFloat16 && x2.is_contiguous() && wc.is_contiguous() && Mr > 0;
-    hipStream_t st = (hipStream_t)stream();
-    if (ctx->saved_data["need_dx"].toBool()) {
-      Tensor dx2 = at::empty({Mr, Kw}, dy2.options());
-      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, Mr, Kw, Nw, false, false, 1, 0, 0, 0, dy2.options(), st)))
-        at::mm_out(dx2, dy2, wc);
-      dx = dx2.view(ctx->saved_data["xshape"].toIntVector());
-    }
-    // dW = dY^T X; long token dimensions are split into S batches (library batched GEMM) and summed in fp32: the plain GEMM has
-    // only a few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
-    const int64_t M = dy2.size(0);
-    const int64_t S = std::min<int64_t>(32, M / 1024);
-    Tensor dw;
-    if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
-      Tensor part = at::empty({S, Nw, Kw}, dy2.options());
-      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, Nw, Kw, M / S, true, false, (int)S,
-                                     (M / S) * Nw, (M / S) * Kw, Nw * Kw, dy2.options(), st)))
-        at::bmm_out(part, dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
-      dw = at::sum(part, {0});   // bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
-    } else {
-      dw = at::empty({Nw, Kw}, dy2.options());
-      if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, Nw, Kw, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
-        at::mm_out(dw, dy2.t(), x2);
-    }
+    if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dy2, wc).view(ctx->saved_data["xshape"].toIntVector());
+    Tensor dw = gemm_dw(dy2, x2);
     const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
     if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
     Tensor db;
     const int64_t bk = ctx->saved_data["b_kind"].toInt();
     if (bk) db = colsum(dy2, bk == 2 ? at::kBFloat16 : at::kFloat);
     return {dx, dw, db, undefined()};
+  }
+};
+
+// h = gelu(x W^T + b) as ONE node (convnext_Block pwconv1 + act, cod.py:1097-1098): the backward computes dpre = dh * gelu'(pre)
+// and the bias gradient sum(dpre) in one pass (dgtd_gelu_bias_bwd) instead of GELU-backward + column-sum + reduce.
+struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const Tensor& b, int64_t dt_code) {
+    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    Tensor x2 = as_rows(x, dt);
+    Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
+    Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
+    Tensor pre = gemm_fwd(x2, wc, bc);
+    Tensor h = at::empty(with_last(x, w.size(0)), pre.options());
+    Tensor h2 = h.view({-1, w.size(0)});
+    at::gelu_out(h2, pre);
+    ctx->save_for_backward({x2, wc, pre});
+    ctx->saved_data["xshape"] = x.sizes().vec();
+    ctx->saved_data["w_bf16"] = w.scalar_type() == at::kBFloat16;
+    ctx->saved_data["b_bf16"] = b.scalar_type() == at::kBFloat16;
+    ctx->saved_data["need_dx"] = x.requires_grad();
+    return h;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x2 = saved[0], &wc = saved[1], &pre = saved[2];
+    Tensor dh = as_rows(g[0], pre.scalar_type());
+    const int64_t rows = pre.size(0), C = pre.size(1);
+    const bool b_bf16 = ctx->saved_data["b_bf16"].toBool();
+    Tensor dpre = at::empty_like(pre), db = at::empty({C}, pre.options().dtype(b_bf16 ? at::kBFloat16 : at::kFloat));
+    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, pre.options().dtype(at::kByte));
+    check(dgtd_gelu_bias_bwd(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), code(db), ws.data_ptr(), rows, (int)C, code(pre),
+                             stream()), "dgtd_gelu_bias_bwd");
+    Tensor dx;
+    if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
+    Tensor dw = gemm_dw(dpre, x2);
+    const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
+    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
+    return {dx, dw, db, undefined()};
+  }
+};
+
+// out = x + s[b] * gamma[c] * (h W^T + b) as ONE node (pwconv2 + layer scale + DropPath + residual, cod.py:1099-1116; attn.proj /
+// Mlp.fc2 + DropPath + residual, cod.py:958-959): the backward computes dy = s*gamma*g, dgamma and the bias gradient sum(dy) in one
+// pass (dgtd_scale_residual_bias_bwd) instead of scale_residual_bwd + column-sum (4 launches -> 2).
+struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& h, const Tensor& w, const Tensor& b, const Tensor& x_, const c10::optional<Tensor>& s_,
+                        const c10::optional<Tensor>& gamma_, int64_t dt_code) {
+    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    const bool has_s = s_.has_value() && s_->defined(), has_g = gamma_.has_value() && gamma_->defined();
+    Tensor h2 = as_rows(h, dt);
+    Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
+    Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
+    Tensor x = (x_.scalar_type() == dt ? x_ : x_.to(dt)).contiguous();
+    Tensor y = gemm_fwd(h2, wc, bc);
+    const int64_t B = x.size(0), C = x.size(-1), rows = x.numel() / C;
+    Tensor s = has_s ? f32(*s_) : Tensor(), g32 = has_g ? f32(*gamma_) : Tensor();
+    Tensor out = at::empty_like(x);
+    check(dgtd_scale_residual_fwd(x.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                  out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
+    ctx->save_for_backward({h2, wc, y, s, g32});
+    ctx->saved_data["hshape"] = h.sizes().vec();
+    ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, w.scalar_type() == at::kBFloat16, b.scalar_type() == at::kBFloat16,
+                                                   has_g && gamma_->scalar_type() == at::kBFloat16, h.requires_grad(), B};
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &h2 = saved[0], &wc = saved[1], &y = saved[2], &s = saved[3], &g32 = saved[4];
+    const auto m = ctx->saved_data["meta"].toIntVector();
+    const bool has_s = m[0], has_g = m[1], w_bf16 = m[2], b_bf16 = m[3], g_bf16 = m[4], need_dh = m[5];
+    Tensor g = gr[0].contiguous();
+    if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
+    const int64_t rows = y.size(0), C = y.size(1), B = m[6];
+    Tensor dy = at::empty_like(y), db = at::empty({C}, y.options().dtype(b_bf16 ? at::kBFloat16 : at::kFloat));
+    Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
+    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, y.options().dtype(at::kByte));
+    check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                       dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, db.data_ptr(), code(db), ws.data_ptr(), rows,
+                                       (int)C, rows / B, code(y), stream()), "dgtd_scale_residual_bias_bwd");
+    Tensor dh;
+    if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
+    Tensor dw = gemm_dw(dy, h2);
+    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
+    if (has_g && g_bf16) dgamma = dgamma.to(at::kBFloat16);
+    return {dh, dw, db, g, undefined(), dgamma, undefined()};
   }
 };
 
@@ -427,6 +530,11 @@ Tensor scale_residual(const Tensor& x, const Tensor& y, const c10::optional<Tens
   return ScaleResidualFn::apply(x, y, s, gamma);
 }
 Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, int64_t dt_code) { return LinearFn::apply(x, w, b, dt_code); }
+Tensor linear_gelu(const Tensor& x, const Tensor& w, const Tensor& b, int64_t dt_code) { return LinearGeluFn::apply(x, w, b, dt_code); }
+Tensor linear_residual(const Tensor& h, const Tensor& w, const Tensor& b, const Tensor& x, const c10::optional<Tensor>& s,
+                       const c10::optional<Tensor>& gamma, int64_t dt_code) {
+  return LinearResidualFn::apply(h, w, b, x, s, gamma, dt_code);
+}
 Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3Fn::apply(x, w, b, relu); }
 Tensor conv3x3_cl(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3ClFn::apply(x, w, b, relu); }
 Tensor prelu(const Tensor& x, const Tensor& a) { return PReLUFn::apply(x, a); }
@@ -441,6 +549,8 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("dwconv_nhwc(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> Tensor", &dwconv_nhwc);
   m.def("scale_residual(Tensor x, Tensor y, Tensor? s, Tensor? gamma) -> Tensor", &scale_residual);
   m.def("linear(Tensor x, Tensor weight, Tensor? bias, int dtype_code) -> Tensor", &linear);
+  m.def("linear_gelu(Tensor x, Tensor weight, Tensor bias, int dtype_code) -> Tensor", &linear_gelu);
+  m.def("linear_residual(Tensor h, Tensor weight, Tensor bias, Tensor x, Tensor? s, Tensor? gamma, int dtype_code) -> Tensor", &linear_residual);
   m.def("conv3x3(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3);
   m.def("conv3x3_cl(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3_cl);
   m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);

@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -169,6 +169,10 @@ class Attention(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
+        return self.proj(self.core(x, H, W))
+
+    def core(self, x, H, W):
+        """Everything up to (not including) the output projection; Block fuses the projection with its residual epilogue."""
         q = self.q(x)
         if self.sr_ratio > 1:  # k == s conv == patchify + GEMM, stays token-major
             w, b = wb(self.sr)
@@ -176,8 +180,7 @@ class Attention(nn.Module):
             r = self.norm(r)
         else:
             r = x
-        o = ops.sra_attention(q, self.kv(r), self.num_heads, self.scale)
-        return self.proj(o)
+        return ops.sra_attention(q, self.kv(r), self.num_heads, self.scale)
 
 
 class DWConv(nn.Module):
@@ -205,7 +208,10 @@ class Mlp(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
-        return self.fc2(self.dwconv(self.fc1(x), H, W, gelu=True))  # dw3x3 + bias + exact GELU in one pass
+        return self.fc2(self.hidden(x, H, W))
+
+    def hidden(self, x, H, W):
+        return self.dwconv(self.fc1(x), H, W, gelu=True)  # dw3x3 + bias + exact GELU in one pass
 
 
 class Block(nn.Module):
@@ -226,6 +232,9 @@ class Block(nn.Module):
         return self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
 
     def forward(self, x, H, W):
+        if _USE["fused_linear"] and x.is_cuda:   # projection / fc2 + DropPath + residual as one node (bias gradient fused in its backward)
+            x = ops.linear_residual(self.attn.core(self.norm1(x), H, W), *wb(self.attn.proj), x, self._scale(x))
+            return ops.linear_residual(self.mlp.hidden(self.norm2(x), H, W), *wb(self.mlp.fc2), x, self._scale(x))
         x = ops.scale_residual(x, self.attn(self.norm1(x), H, W), self._scale(x))   # x + DropPath(attn), one pass
         return ops.scale_residual(x, self.mlp(self.norm2(x), H, W), self._scale(x))
 
@@ -245,8 +254,11 @@ class convnext_Block(nn.Module):
 
     def forward_nhwc(self, x):
         y = ops.dwconv_nhwc(x, *wb(self.dwconv))
-        y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
         s = self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
+        if _USE["fused_linear"] and x.is_cuda:   # pwconv1+GELU and pwconv2+gamma+DropPath+residual as two nodes with fused backward passes
+            h = ops.linear_gelu(self.norm(y), *wb(self.pwconv1))
+            return ops.linear_residual(h, *wb(self.pwconv2), x, s, self.gamma)
+        y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
         return ops.scale_residual(x, y, s, self.gamma)   # x + DropPath(gamma * y) in one pass
 
     def forward(self, x):  # reference contract: NCHW in, NCHW out

@@ -146,3 +146,34 @@ def linear(x, w, b=None):
             with torch.autocast("cuda", enabled=False):
                 return nat.linear(x, w, b, 1 if dt == torch.bfloat16 else 0)
     return _LinearFn.apply(x, w, b)
+
+
+def _native_dt(x):
+    """(native ops, dtype code) when the C++ nodes can take this call, else (None, None)."""
+    nat = _native.ops()
+    if nat is None or not x.is_cuda or not SPLITK_WGRAD:
+        return None, None
+    dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        return None, None
+    return nat, (1 if dt == torch.bfloat16 else 0)
+
+
+def linear_gelu(x, w, b):
+    """gelu(x W^T + b) (convnext_Block pwconv1 + act, cod.py:1097-1098).  With the C++ bindings it is ONE autograd node whose
+    backward fuses GELU' with the bias-gradient column sum (dgtd_gelu_bias_bwd); otherwise the composition of the separate ops."""
+    nat, code = _native_dt(x)
+    if nat is not None and b is not None:
+        with torch.autocast("cuda", enabled=False):
+            return nat.linear_gelu(x, w, b, code)
+    return torch.nn.functional.gelu(linear(x, w, b))
+
+
+def linear_residual(h, w, b, x, s=None, gamma=None):
+    """x + s[b] * gamma[c] * (h W^T + b): Linear + layer scale + DropPath + residual (cod.py:1099-1116, :958-959).  With the C++
+    bindings ONE autograd node whose backward produces dy, dgamma and the bias gradient in one pass."""
+    nat, code = _native_dt(h)
+    if nat is not None and b is not None:
+        with torch.autocast("cuda", enabled=False):
+            return nat.linear_residual(h, w, b, x, s, gamma, code)
+    return scale_residual(x, linear(h, w, b), s, gamma)

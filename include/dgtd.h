@@ -90,6 +90,17 @@ int64_t dgtd_colsum_workspace(int C);
 int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy,
                             float* dgamma, void* workspace, int64_t rows, int C, int64_t rows_per_sample,
                             dgtd_dtype dt, dgtd_stream st);
+/* Backward of a Linear fused with the op that consumes its output: the bias gradient of the Linear is the column sum of the very
+ * gradient these kernels write, so both come from one pass (workspace: dgtd_colsum2_workspace(C) bytes).
+ * residual epilogue (cod.py:1112-1116 after pwconv2 :1099; cod.py:958-959 after attn.proj :874 / Mlp.fc2 :832):
+ *   dy = s*gamma*g (overwritten), dgamma = sum s*g*y (fp32; NULL iff gamma is NULL), dbias[C] (dtype bias_dt) = sum_r dy.
+ * GELU (cod.py:1098 between pwconv1 and pwconv2): dpre = g * gelu'(pre) (overwritten), dbias[C] = sum_r dpre.                    */
+int64_t dgtd_colsum2_workspace(int C);
+int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
+                                 void* dbias, dgtd_dtype bias_dt, void* workspace, int64_t rows, int C,
+                                 int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st);
+int dgtd_gelu_bias_bwd(const void* g, const void* pre, void* dpre, void* dbias, dgtd_dtype bias_dt, void* workspace,
+                       int64_t rows, int C, dgtd_dtype dt, dgtd_stream st);
 /* out [C] (dtype out_dt, fp32 accumulation) = column sums of x [rows, C]: the bias gradient of nn.Linear
  * (cod.py:829,832,872-875,1097,1099), written in the dtype of the bias it belongs to.                                   */
 int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt,

@@ -343,3 +343,59 @@ def test_bilinear_resize_nhwc(dgtd, B, C, Hi, Wi, Ho, Wo, align, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
     torch.testing.assert_close(hx.float(), gx, atol=tol * 8, rtol=tol)
+
+
+# ---------------------------------------------------------------------------------------------- Linear fused with its consumer
+@pytest.mark.parametrize("rows,K,N", [(1024, 128, 512), (8192, 512, 2048), (300, 64, 256)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_gelu_fused_backward(dgtd, rows, K, N, dtype):
+    """gelu(x W^T + b): value, dx, dW and the bias gradient (GELU' fused with the column sum) vs fp32 torch."""
+    x = _rand(2, rows // 2, K, seed=1, dtype=dtype)
+    w = (_rand(N, K, seed=2) / math.sqrt(K)).to(dtype).requires_grad_()
+    b = (0.1 * _rand(N, seed=3)).to(dtype).requires_grad_()
+    g = _rand(2, rows // 2, N, seed=4, dtype=dtype)
+    xr, wr, br = x.float().requires_grad_(), w.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    ref = F.gelu(F.linear(xr, wr, br))
+    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), g.float())
+    xs = x.clone().requires_grad_()
+    y = dgtd.ops.linear_gelu(xs, w, b)
+    hx, hw, hb = torch.autograd.grad(y, (xs, w, b), g)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
+    torch.testing.assert_close(hw.float(), gw, atol=tol * math.sqrt(rows), rtol=tol)
+    torch.testing.assert_close(hb.float(), gb, atol=tol * math.sqrt(rows), rtol=tol)
+
+
+@pytest.mark.parametrize("rows,K,N", [(1024, 512, 128), (8192, 2048, 512), (300, 256, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_s,with_g", [(True, True), (True, False), (False, False)])
+def test_linear_residual_fused_backward(dgtd, rows, K, N, dtype, with_s, with_g):
+    """x + s*gamma*(h W^T + b): value and every gradient (dh, dW, db, dx, dgamma) vs fp32 torch."""
+    B = 2
+    h = _rand(B, rows // B, K, seed=1, dtype=dtype)
+    x = _rand(B, rows // B, N, seed=5, dtype=dtype)
+    w = (_rand(N, K, seed=2) / math.sqrt(K)).to(dtype).requires_grad_()
+    b = (0.1 * _rand(N, seed=3)).to(dtype).requires_grad_()
+    s = torch.tensor([0.0, 1.25], device="cuda") if with_s else None
+    gamma = (0.5 + 0.1 * _rand(N, seed=6)).requires_grad_() if with_g else None
+    g = _rand(B, rows // B, N, seed=4, dtype=dtype)
+    hr, xr = h.float().requires_grad_(), x.float().requires_grad_()
+    wr, br = w.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    y = F.linear(hr, wr, br)
+    if with_g:
+        y = y * gamma
+    if with_s:
+        y = y * s.view(B, 1, 1)
+    ref = xr + y
+    ins = [hr, xr, wr, br] + ([gamma] if with_g else [])
+    rg = torch.autograd.grad(ref, ins, g.float())
+    hs, xs = h.clone().requires_grad_(), x.clone().requires_grad_()
+    out = dgtd.ops.linear_residual(hs, w, b, xs, s, gamma)
+    got = torch.autograd.grad(out, [hs, xs, w, b] + ([gamma] if with_g else []), g)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(got[0].float(), rg[0], atol=tol, rtol=tol)
+    torch.testing.assert_close(got[1].float(), rg[1], atol=tol, rtol=tol)
+    for a_, r_ in zip(got[2:], rg[2:]):
+        torch.testing.assert_close(a_.float(), r_, atol=tol * math.sqrt(rows), rtol=tol)
