@@ -93,27 +93,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
   }
 }
 
-// ws [nblocks][C] -> out[C]; one workgroup per 64 columns, 4 waves over the rows, fixed summation order
+// ws [nblocks][C] -> out[C]; one workgroup per 32 columns x 8 row groups, fixed summation order
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, void* __restrict__ out, int out_bf16, int nblocks, int C) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (col < C) {
     const float* p = ws + col;
-    int b = wave;
-    for (; b + 28 < nblocks; b += 32) {
-      const float v0 = p[(size_t)b * C], v1 = p[(size_t)(b + 4) * C], v2 = p[(size_t)(b + 8) * C], v3 = p[(size_t)(b + 12) * C];
-      const float v4 = p[(size_t)(b + 16) * C], v5 = p[(size_t)(b + 20) * C], v6 = p[(size_t)(b + 24) * C], v7 = p[(size_t)(b + 28) * C];
-      s0 += ((v0 + v1) + (v2 + v3));
-      s1 += ((v4 + v5) + (v6 + v7));
+    int b = rgp;
+    for (; b + 24 < nblocks; b += 32) {
+      s0 += p[(size_t)b * C] + p[(size_t)(b + 8) * C];
+      s1 += p[(size_t)(b + 16) * C] + p[(size_t)(b + 24) * C];
     }
-    for (; b < nblocks; b += 4) s0 += p[(size_t)b * C];
+    for (; b < nblocks; b += 8) s0 += p[(size_t)b * C];
   }
-  part[wave][lane] = s0 + s1;
+  part[rgp][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && col < C) {
-    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (rgp == 0 && col < C) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][lane];
     if (out_bf16) ((bf16_t*)out)[col] = (bf16_t)v;
     else ((float*)out)[col] = v;
   }
@@ -138,7 +138,7 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
   hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
   if (MODE != 2) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, out, out_bf16, gx, C);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, out, out_bf16, gx, C);
     DGTD_CHECK_LAUNCH(who);
   }
   return 0;
@@ -214,24 +214,29 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ g, c
 // ws [nblocks][2C] -> outA[C] fp32 (columns < C; skipped when outA is NULL) and outB[C] (fp32 or bf16); fixed summation order
 __global__ __launch_bounds__(256) void colsum2_reduce_kernel(const float* __restrict__ ws, float* __restrict__ outA, void* __restrict__ outB,
                                                              int outB_bf16, int nblocks, int C) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;              // over 2C columns
+  // 32 columns x 8 row groups per workgroup: twice the workgroups of a 64-column layout (the partial buffer is small, the kernel
+  // is latency-bound), 128-byte contiguous reads per row group
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + lane;              // over 2C columns
   const bool live = col < 2 * C && (col >= C || outA != nullptr);
   float s0 = 0.f, s1 = 0.f;
   if (live) {
     const float* p = ws + col;
-    int b = wave;
-    for (; b + 12 < nblocks; b += 16) {
-      s0 += p[(size_t)b * 2 * C] + p[(size_t)(b + 4) * 2 * C];
-      s1 += p[(size_t)(b + 8) * 2 * C] + p[(size_t)(b + 12) * 2 * C];
+    const size_t rs = (size_t)2 * C;
+    int b = rgp;
+    for (; b + 24 < nblocks; b += 32) {
+      s0 += p[b * rs] + p[(b + 8) * rs];
+      s1 += p[(b + 16) * rs] + p[(b + 24) * rs];
     }
-    for (; b < nblocks; b += 4) s0 += p[(size_t)b * 2 * C];
+    for (; b < nblocks; b += 8) s0 += p[b * rs];
   }
-  part[wave][lane] = s0 + s1;
+  part[rgp][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && live) {
-    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (rgp == 0 && live) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][lane];
     if (col < C) outA[col] = v;
     else if (outB_bf16) ((bf16_t*)outB)[col - C] = (bf16_t)v;
     else ((float*)outB)[col - C] = v;
@@ -249,7 +254,7 @@ int colsum2_launch(const void* g, const void* y, const float* s, const float* ga
   const size_t lds = (size_t)256 * V * sizeof(float);
   hipLaunchKernelGGL((colsum2_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(colsum2_reduce_kernel, dim3((int)cdiv(2 * C, 64)), dim3(256), 0, st, (const float*)ws, outA, outB, outB_bf16, gx, C);
+  hipLaunchKernelGGL(colsum2_reduce_kernel, dim3((int)cdiv(2 * C, 32)), dim3(256), 0, st, (const float*)ws, outA, outB, outB_bf16, gx, C);
   DGTD_CHECK_LAUNCH(who);
   return 0;
 }

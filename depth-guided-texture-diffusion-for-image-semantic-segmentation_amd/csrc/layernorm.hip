@@ -204,26 +204,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // the four waves meet in LDS.  Deterministic (fixed summation order), unlike an atomic flush.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nblocks, int C) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  // 32 columns x 8 row groups per workgroup (the partial buffer is small and the kernel latency-bound: more, narrower workgroups)
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (col < 2 * C) {
     const size_t rs = (size_t)2 * C;
     const float* p = ws + col;
-    int b = wave;
-    for (; b + 28 < nblocks; b += 32) {   // 8 independent loads in flight per lane, fixed summation order
-      const float v0 = p[(size_t)b * rs], v1 = p[(size_t)(b + 4) * rs], v2 = p[(size_t)(b + 8) * rs], v3 = p[(size_t)(b + 12) * rs];
-      const float v4 = p[(size_t)(b + 16) * rs], v5 = p[(size_t)(b + 20) * rs], v6 = p[(size_t)(b + 24) * rs], v7 = p[(size_t)(b + 28) * rs];
+    int b = rgp;
+    for (; b + 56 < nblocks; b += 64) {   // 8 independent loads in flight per lane, fixed summation order
+      const float v0 = p[(size_t)b * rs], v1 = p[(size_t)(b + 8) * rs], v2 = p[(size_t)(b + 16) * rs], v3 = p[(size_t)(b + 24) * rs];
+      const float v4 = p[(size_t)(b + 32) * rs], v5 = p[(size_t)(b + 40) * rs], v6 = p[(size_t)(b + 48) * rs], v7 = p[(size_t)(b + 56) * rs];
       s0 += ((v0 + v1) + (v2 + v3));
       s1 += ((v4 + v5) + (v6 + v7));
     }
-    for (; b < nblocks; b += 4) s0 += p[(size_t)b * rs];
+    for (; b < nblocks; b += 8) s0 += p[(size_t)b * rs];
   }
-  part[wave][lane] = s0 + s1;
+  part[rgp][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && col < 2 * C) {
-    const float s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (rgp == 0 && col < 2 * C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += part[k][lane];
     if (col < C) dgamma[col] = s; else dbeta[col - C] = s;
   }
 }
@@ -265,7 +268,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
   switch (g.npl) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; default: LN_BWD(4); }
 #undef LN_BWD
   DGTD_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((int)cdiv(2 * C, 64)), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, grid, C);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((int)cdiv(2 * C, 32)), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, grid, C);
   DGTD_CHECK_LAUNCH("layernorm_bwd_reduce");
   return 0;
 }
