@@ -313,8 +313,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
     const size_t ps = (size_t)32 * 9 * (CB * 32);
     float s0 = 0.f, s1 = 0.f;
     int q = 0;
-    for (; q + 1 < P; q += 2) { s0 += pp[q * ps]; s1 += pp[(q + 1) * ps]; }
-    if (q < P) s0 += pp[q * ps];
+    for (; q + 7 < P; q += 8) {      // 8 independent loads in flight, fixed summation order
+      const float v0 = pp[q * ps], v1 = pp[(q + 1) * ps], v2 = pp[(q + 2) * ps], v3 = pp[(q + 3) * ps];
+      const float v4 = pp[(q + 4) * ps], v5 = pp[(q + 5) * ps], v6 = pp[(q + 6) * ps], v7 = pp[(q + 7) * ps];
+      s0 += (v0 + v1) + (v2 + v3);
+      s1 += (v4 + v5) + (v6 + v7);
+    }
+    for (; q < P; ++q) s0 += pp[q * ps];
     dw[i] = (bf16_t)(s0 + s1);
   }
   if (db && i < (long)Z * Co) {

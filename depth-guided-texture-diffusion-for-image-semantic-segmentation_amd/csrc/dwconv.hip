@@ -120,22 +120,28 @@ template <> struct Pair<bf16_t> { typedef bf16_t type __attribute__((ext_vector_
 // ws[gridDim.x][K*K + 1][C] -> out[(K*K + 1) * C] (= { dw_t | db }); fixed summation order, no atomics
 __global__ __launch_bounds__(256) void dwconv_bww_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks,
                                                                 int ncols) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  __shared__ float part[8][32];     // 32 columns x 8 row groups per workgroup, 8 loads in flight per lane
+  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (col < ncols) {
     const float* p = ws + col;
-    int b = wave;
-    for (; b + 12 < nblocks; b += 16) {
-      const float v0 = p[(size_t)b * ncols], v1 = p[(size_t)(b + 4) * ncols], v2 = p[(size_t)(b + 8) * ncols], v3 = p[(size_t)(b + 12) * ncols];
-      s0 += v0 + v1; s1 += v2 + v3;
+    int b = rgp;
+    for (; b + 56 < nblocks; b += 64) {
+      const float v0 = p[(size_t)b * ncols], v1 = p[(size_t)(b + 8) * ncols], v2 = p[(size_t)(b + 16) * ncols], v3 = p[(size_t)(b + 24) * ncols];
+      const float v4 = p[(size_t)(b + 32) * ncols], v5 = p[(size_t)(b + 40) * ncols], v6 = p[(size_t)(b + 48) * ncols], v7 = p[(size_t)(b + 56) * ncols];
+      s0 += (v0 + v1) + (v2 + v3); s1 += (v4 + v5) + (v6 + v7);
     }
-    for (; b < nblocks; b += 4) s0 += p[(size_t)b * ncols];
+    for (; b < nblocks; b += 8) s0 += p[(size_t)b * ncols];
   }
-  part[wave][lane] = s0 + s1;
+  part[rgp][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && col < ncols) out[col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (rgp == 0 && col < ncols) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][lane];
+    out[col] = v;
+  }
 }
 
 // One workgroup = K waves; wave w owns filter row ky = w.  All K waves walk the SAME column of strips (fixed image, x-range and
@@ -276,7 +282,7 @@ int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* 
                      has_bias, B, H, W, C, ys);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
   const int ncols = (K * K + 1) * C;
-  hipLaunchKernelGGL(dwconv_bww_reduce_kernel, dim3((int)cdiv(ncols, 64)), dim3(256), 0, s, (const float*)workspace, grads, gx, ncols);
+  hipLaunchKernelGGL(dwconv_bww_reduce_kernel, dim3((int)cdiv(ncols, 32)), dim3(256), 0, s, (const float*)workspace, grads, gx, ncols);
   DGTD_CHECK_LAUNCH("dwconv_bww_reduce");
   return 0;
 }
