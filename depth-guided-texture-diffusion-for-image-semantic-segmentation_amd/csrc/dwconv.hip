@@ -168,41 +168,44 @@ __global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __re
   float acc[K][2], accb[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < K; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
-  for (int yy0 = y_begin; yy0 < y_end; ++yy0) {
-    const int yy = yy0 + ky - P;
-    if (yy < 0 || yy >= H) continue;                 // wave-uniform
-    float g[TX][2];
+  // rows of this wave: yy = yy0 + ky - P must lie inside the image
+  const int ya = max(y_begin, P - ky), yb = min(y_end, H + P - ky);
+  const bool interior = x0 - P >= 0 && x0 + TX + P <= W;      // wave-uniform: straight-line loads
+  // The packed (2 x bf16 / 2 x fp32) values of the NEXT row are fetched before the FMAs of the current one: a wave otherwise
+  // alternates between 22 loads and ~150 VALU instructions with the full L2 latency exposed in between (6 waves per SIMD do
+  // not cover it); the raw pairs cost one register each, the converted floats exist only for the row being processed.
+  PT graw[TX], inraw[TX + K - 1], gnext[TX], innext[TX + K - 1];
+  auto fetch = [&](int yy0, PT* gr, PT* ir) {
     const T* grow = du + (((size_t)b * H + yy0) * W + x0) * C + c0;
-    const T* row = x + (((size_t)b * H + yy) * W + x0 - P) * C + c0;
-    float in[TX + K - 1][2];
-    if (x0 - P >= 0 && x0 + TX + P <= W) {          // interior strip (wave-uniform): straight-line loads, 32-bit offsets
+    const T* row = x + (((size_t)b * H + (yy0 + ky - P)) * W + x0 - P) * C + c0;
+    if (interior) {
 #pragma unroll
-      for (int t = 0; t < TX; ++t) {
-        PT v = *reinterpret_cast<const PT*>(grow + t * C);
-        g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
-      }
+      for (int t = 0; t < TX; ++t) gr[t] = *reinterpret_cast<const PT*>(grow + t * C);
 #pragma unroll
-      for (int i = 0; i < TX + K - 1; ++i) {
-        PT v = *reinterpret_cast<const PT*>(row + i * C);
-        in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
-      }
+      for (int i = 0; i < TX + K - 1; ++i) ir[i] = *reinterpret_cast<const PT*>(row + i * C);
     } else {
 #pragma unroll
       for (int t = 0; t < TX; ++t) {
-        if (x0 + t < W) {
-          PT v = *reinterpret_cast<const PT*>(grow + t * C);
-          g[t][0] = (float)v[0]; g[t][1] = (float)v[1];
-        } else { g[t][0] = 0.f; g[t][1] = 0.f; }
+        PT z; z[0] = (T)0.f; z[1] = (T)0.f;
+        gr[t] = (x0 + t < W) ? *reinterpret_cast<const PT*>(grow + t * C) : z;
       }
 #pragma unroll
       for (int i = 0; i < TX + K - 1; ++i) {
         const int xx = x0 + i - P;
-        if (xx >= 0 && xx < W) {
-          PT v = *reinterpret_cast<const PT*>(row + i * C);
-          in[i][0] = (float)v[0]; in[i][1] = (float)v[1];
-        } else { in[i][0] = 0.f; in[i][1] = 0.f; }
+        PT z; z[0] = (T)0.f; z[1] = (T)0.f;
+        ir[i] = (xx >= 0 && xx < W) ? *reinterpret_cast<const PT*>(row + i * C) : z;
       }
     }
+  };
+  if (ya < yb) fetch(ya, graw, inraw);
+  for (int yy0 = ya; yy0 < yb; ++yy0) {
+    const bool more = yy0 + 1 < yb;
+    if (more) fetch(yy0 + 1, gnext, innext);
+    float g[TX][2], in[TX + K - 1][2];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) { g[t][0] = (float)graw[t][0]; g[t][1] = (float)graw[t][1]; }
+#pragma unroll
+    for (int i = 0; i < TX + K - 1; ++i) { in[i][0] = (float)inraw[i][0]; in[i][1] = (float)inraw[i][1]; }
     if (ky == P) {
 #pragma unroll
       for (int t = 0; t < TX; ++t) { accb[0] += g[t][0]; accb[1] += g[t][1]; }
@@ -214,6 +217,12 @@ __global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __re
         acc[kx][0] += g[t][0] * in[t + kx][0];
         acc[kx][1] += g[t][1] * in[t + kx][1];
       }
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < TX; ++t) graw[t] = gnext[t];
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) inraw[i] = innext[i];
+    }
   }
   // ws[blockIdx.x][K*K + 1][C]: this wave's K tap rows (+ the bias row from the centre wave), plain 8-byte stores
   typedef float f32x2 __attribute__((ext_vector_type(2)));
