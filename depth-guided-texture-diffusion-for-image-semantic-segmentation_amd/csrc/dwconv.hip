@@ -59,24 +59,31 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 #pragma unroll
       for (int t = 0; t < TX; ++t) acc[t][j] = bv;
     }
-#pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {   // not unrolled: keeps ~1 row of taps live -> high occupancy hides the L2 latency
+    // filter rows one at a time (keeps ~1 row of taps live); the raw 16-byte vectors of the NEXT row are requested before the
+    // FMAs of the current one so that the L2 latency of a row is covered by the arithmetic of its predecessor
+    VT rawc[TX + K - 1], rawn[TX + K - 1];
+    auto fetch = [&](int ky, VT* dst) {
       const int yy = yy0 + ky - P;
-      if (yy < 0 || yy >= H) continue;
-      const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
-      float in[TX + K - 1][V];
+      const bool rowok = yy >= 0 && yy < H;
+      const T* row = x + (((size_t)b * H + (rowok ? yy : 0)) * W) * C + c0;
 #pragma unroll
       for (int i = 0; i < TX + K - 1; ++i) {
         const int xx = x0 + i - P;
-        if (xx >= 0 && xx < W) {
-          VT v = *reinterpret_cast<const VT*>(row + (size_t)xx * C);
+        VT z;
 #pragma unroll
-          for (int j = 0; j < V; ++j) in[i][j] = (float)v[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < V; ++j) in[i][j] = 0.f;
-        }
+        for (int j = 0; j < V; ++j) z[j] = (T)0.f;
+        dst[i] = (rowok && xx >= 0 && xx < W) ? *reinterpret_cast<const VT*>(row + (size_t)xx * C) : z;
       }
+    };
+    fetch(0, rawc);
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      if (ky + 1 < K) fetch(ky + 1, rawn);
+      float in[TX + K - 1][V];
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i)
+#pragma unroll
+        for (int j = 0; j < V; ++j) in[i][j] = (float)rawc[i][j];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         float wv[V];
@@ -91,6 +98,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 #pragma unroll
           for (int j = 0; j < V; ++j) acc[t][j] += in[t + kx][j] * wv[j];
       }
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) rawc[i] = rawn[i];
     }
     T* orow = y + (((size_t)b * H + yy0) * W) * C + c0;
 #pragma unroll
