@@ -5,6 +5,7 @@
 // device thread), so a call is one hipblasLtMatmul.  Library GEMM, not a hand-written kernel: plain GEMMs belong to hipBLASLt.
 #pragma once
 #include <ATen/ATen.h>
+#include <hip/hip_runtime_api.h>
 #include <hipblaslt/hipblaslt.h>
 
 #include <cstdlib>
@@ -46,6 +47,11 @@ constexpr size_t kWorkspace = 64u << 20;
 
 inline bool enabled() {
   static const bool on = [] { const char* e = std::getenv("DGTD_DIRECT_GEMM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+inline bool tune() {   // DGTD_GEMM_TUNE=1: pick among the heuristic's candidates by measurement (measured: no gain on this model, off by default)
+  static const bool on = [] { const char* e = std::getenv("DGTD_GEMM_TUNE"); return e && e[0] == '1'; }();
   return on;
 }
 
@@ -102,11 +108,39 @@ inline bool matmul_bf16(const void* A, const void* B, void* D, const void* bias,
       set_batch(p.d, batch, sD);
     }
     if (good) {
-      hipblasLtMatmulHeuristicResult_t res[1];
+      constexpr int kTry = 8;
+      hipblasLtMatmulHeuristicResult_t res[kTry];
       int found = 0;
-      good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, 1, res, &found)) && found > 0 &&
-             res[0].workspaceSize <= kWorkspace;
-      if (good) p.algo = res[0].algo;
+      good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, tune() ? kTry : 1, res, &found)) && found > 0;
+      int best = -1;
+      if (good && found > 1) {
+        // one-time selection among the heuristic's candidates by measurement (the top-1 pick is not always the fastest for the
+        // skinny token-major shapes of this model): 1 warm-up + 3 timed runs each, on the caller's stream
+        const float alpha = 1.f, beta = 0.f;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float best_ms = 1e30f;
+        for (int i = 0; i < found; ++i) {
+          if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kWorkspace) continue;
+          bool run_ok = true;
+          for (int r = 0; r < 4 && run_ok; ++r) {
+            if (r == 1) hipEventRecord(e0, st);
+            run_ok = ok(hipblasLtMatmul(c.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, D, p.d, D, p.d, &res[i].algo, c.ws.data_ptr(),
+                                        kWorkspace, st));
+          }
+          hipEventRecord(e1, st);
+          hipEventSynchronize(e1);
+          float ms = 0.f;
+          if (run_ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = i; }
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+      } else if (good && res[0].workspaceSize <= kWorkspace) {
+        best = 0;
+      }
+      good = best >= 0;
+      if (good) p.algo = res[best].algo;
     }
     p.ok = good;
     it = c.plans.emplace(key, p).first;
