@@ -75,6 +75,8 @@ def main():
         import __graft_entry__ as _ge
         if int(os.environ.get("LOCAL_RANK", 0)) == 0:
             _ge.build()
+        else:
+            _ge.wait_for_build()     # local rank 0 (re)builds; the others only load finished libraries
     except Exception as e:  # keep going with the libraries already in the tree; a missing library still fails loudly below
         print(f"[bench] build() skipped: {e}", file=sys.stderr, flush=True)
     import dgtd
