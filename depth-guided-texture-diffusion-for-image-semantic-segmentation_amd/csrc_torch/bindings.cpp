@@ -3,6 +3,7 @@
 // pointers on the current HIP stream, one autograd node per op.  Host plumbing only (no device code here): it exists because the
 // training step is host-bound in eager Python (~1600 Python autograd.Function calls per step); these nodes cost a few microseconds.
 #include <ATen/ATen.h>
+#include <cstdlib>
 #include <c10/hip/HIPStream.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
@@ -218,7 +219,8 @@ inline Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                    
   const int64_t M = dy2.size(0), N = dy2.size(1), K = x2.size(1);
   const bool bf = dy2.scalar_type() == at::kBFloat16 && x2.is_contiguous() && M > 0;
   hipStream_t st = (hipStream_t)stream();
-  const int64_t S = std::min<int64_t>(32, M / 1024);
+  static const int64_t max_split = [] { const char* e = std::getenv("DGTD_WGRAD_SPLIT"); return e ? (int64_t)std::atol(e) : (int64_t)32; }();
+  const int64_t S = std::min<int64_t>(max_split, M / 1024);
   if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
     Tensor part = at::empty({S, N, K}, dy2.options());
     if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, N, K, M / S, true, false, (int)S, (M / S) * N,
