@@ -90,7 +90,10 @@ def main():
     net = dgtd.nn.cod(compute_dtype=dtype).to(dev).train()   # random init of the reference architecture, DropPath active
     dgtd.dist.broadcast_parameters(net)
     reducer = dgtd.dist.GradReducer(net, working_dtype=dtype)
-    opt = dgtd.runner.build_optimizer(net)
+    flat_opt = os.environ.get("DGTD_FLAT_ADAMW", "1") != "0"
+    # AdamW over the reducer's flat buckets (one launch per lr run, bf16 working copies rewritten in the same pass), or torch's
+    # fused multi-tensor AdamW + one cast per bucket
+    opt = dgtd.runner.FlatAdamW(reducer) if flat_opt else dgtd.runner.build_optimizer(net)
     data = dgtd.runner.SyntheticRGBD(args.size, args.batch, rank=rank, device=dev)
     batches = [data.batch_at(i) for i in range(2)]  # resident in HBM before timing
 
@@ -105,7 +108,8 @@ def main():
         loss = fwd_bwd(b)
         reducer.finish()
         opt.step()
-        reducer.refresh_working()
+        if not flat_opt:
+            reducer.refresh_working()
         return loss
 
     def barrier():

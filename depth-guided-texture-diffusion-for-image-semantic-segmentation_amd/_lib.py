@@ -46,6 +46,7 @@ SIGNATURES = {
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_bwd_workspace": (_i64, [_i]),
     "dgtd_diffuse_tail_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _vp]),
+    "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "dgtd_prelu_fwd": (_i, [_vp, _fp, _vp, _i64, _i, _vp]),
     "dgtd_prelu_bwd": (_i, [_vp, _vp, _fp, _vp, _fp, _i64, _i, _vp]),
     "dgtd_ca_gate_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),

@@ -114,7 +114,7 @@ class GradReducer:
         rest = [(n, p) for n, p in items if id(p) not in castable]
         n_work, n_rest = sum(p.numel() for _, p in work), sum(p.numel() for _, p in rest)
         flat = torch.zeros(n_work + n_rest, dtype=torch.float32, device=dev)          # fp32 gradients
-        mflat = torch.empty(n_work, dtype=torch.float32, device=dev) if n_work else None  # fp32 masters (castable part)
+        mflat = torch.empty(n_work + n_rest, dtype=torch.float32, device=dev)            # fp32 masters of the whole bucket (flat: one AdamW launch per run)
         wflat = torch.empty(n_work, dtype=self.working_dtype, device=dev) if n_work else None
         masters, leaves, gviews, nhwc = [], [], [], []
         off = 0
@@ -147,10 +147,14 @@ class GradReducer:
                     p.requires_grad_(False)      # the master no longer takes part in autograd
                     leaves.append(leaf)
                 else:
+                    mv = mflat[off:off + n].view_as(p)   # re-homed as well: the flat optimizer updates the bucket in place
+                    mv.copy_(p.data)
+                    p.data = mv
                     leaves.append(p)
                 off += n
         self.buckets.append({"flat": flat, "mflat": mflat, "wflat": wflat, "n_work": n_work, "k_work": len(work),
                              "masters": masters, "leaves": leaves, "gviews": gviews, "nhwc": nhwc,
+                             "names": [n_ for n_, _ in work + rest], "sizes": [p_.numel() for _, p_ in work + rest],
                              "pending": len(items), "n": len(items), "done": False})
 
     # ------------------------------------------------------------------ per step
@@ -159,7 +163,7 @@ class GradReducer:
         """master fp32 -> working copy: ONE cast kernel per bucket (call after optimizer.step())."""
         for b in self.buckets:
             if b["wflat"] is not None:
-                b["wflat"].copy_(b["mflat"])
+                b["wflat"].copy_(b["mflat"][:b["n_work"]])
 
     def zero_grad(self) -> None:
         """Replaces optimizer.zero_grad(): leaves get .grad = None so autograd hands gradients over without an

@@ -181,6 +181,13 @@ int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co)
 int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
                        int H, int W, int Ci, int Co, int shared_x, dgtd_stream s);
 
+/* ---- AdamW over one contiguous run of a flat fp32 parameter bucket (+ the bf16 working copy in the same pass) ----
+ * replaces torch.optim.AdamW(fused) per the reference's optim_wrapper (config/sod.yml:56-76: AdamW, weight_decay 0.1, per-prefix
+ * lr multipliers: one call per run of equal lr).  p, g, m, v fp32 [n] at the same 16-byte phase; w_bf16 [n] or NULL.
+ * p *= 1-lr*wd; m += (1-b1)(g-m); v = b2 v + (1-b2) g*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); w = bf16(p).               */
+int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float bias_correction1, float bias_correction2, dgtd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

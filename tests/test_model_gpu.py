@@ -198,3 +198,48 @@ def test_tier_b_backbone_builds_and_trains(dgtd):
     loss = net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"]
     loss.backward()
     assert torch.isfinite(loss) and net.hitnet.backbone.block3[17].attn.q.weight.grad is not None
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """dgtd.runner.FlatAdamW over the reducer's flat buckets == torch.optim.AdamW (fused) with the same lr multipliers, after
+    4 steps on a small module, including the bf16 working copies it rewrites."""
+    import copy
+    import dgtd
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = dgtd.nn.modules.Linear(64, 96)
+            self.c = dgtd.nn.modules.Conv2d(8, 8, 3, padding=1)
+            self.n = torch.nn.LayerNorm(96)
+            self.hitnet_backbone = dgtd.nn.modules.Linear(96, 33)   # odd sizes: unaligned run boundaries
+
+        def forward(self, x, img):
+            return self.hitnet_backbone(self.n(self.a(x))).float().sum() + self.c(img).float().sum()
+
+    keys = {"hitnet_backbone": 0.2}
+    n1 = Net().cuda()
+    n2 = copy.deepcopy(n1)
+    r1 = dgtd.dist.GradReducer(n1, working_dtype=torch.bfloat16, exclude_prefixes=())
+    r2 = dgtd.dist.GradReducer(n2, working_dtype=torch.bfloat16, exclude_prefixes=())
+    o1 = dgtd.runner.FlatAdamW(r1, lr=1e-2, weight_decay=0.1, custom_keys=keys)
+    o2 = dgtd.runner.build_optimizer(n2, lr=1e-2, weight_decay=0.1, custom_keys=keys)
+    # identical gradients are written into both reducers' flat buckets (a model in the loop would amplify 1-ulp differences
+    # through the bf16 working copies); torch's AdamW reads them through the masters' .grad views
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(4):
+        for b1, b2 in zip(r1.buckets, r2.buckets):
+            grad = torch.randn(b1["flat"].shape, device="cuda", generator=g) * 0.1
+            b1["flat"].copy_(grad)
+            b2["flat"].copy_(grad)
+        o1.step()
+        o2.step()
+        r2.refresh_working()
+    for (k, p1), (_, p2) in zip(n1.named_parameters(), n2.named_parameters()):
+        torch.testing.assert_close(p1, p2, atol=1e-6, rtol=1e-5, msg=lambda m: f"{k}: {m}")
+    for b1, b2 in zip(r1.buckets, r2.buckets):   # working copies: bf16 of (nearly) the same masters, at most one bf16 ulp apart
+        torch.testing.assert_close(b1["wflat"].float(), b2["wflat"].float(), atol=1e-3, rtol=8e-3)
+    sd = o1.state_dict()
+    o1.load_state_dict(sd)
+    assert o1.steps == 4
