@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const T* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(da, red[0] + red[1] + red[2] + red[3]);
 }
 
-// pooled[b][c] += sum over a slice of the HW rows of a[b][hw][c] (* optional second factor bfac)   (atomics: B*C addresses, few adders)
+// partial[x][b][c] = sum over slice x of the HW rows of a[b][hw][c] (* optional second factor bfac); the gridDim.x slices of a sample
+// are summed in a fixed order by the per-sample MLP kernels (deterministic, nothing to zero)
 template <typename T, bool PRODUCT>
 __global__ __launch_bounds__(256) void pooled_sum_kernel(const T* __restrict__ a, const T* __restrict__ bfac, float* __restrict__ pooled,
                                                          int HW, int C) {
@@ -67,17 +68,22 @@ __global__ __launch_bounds__(256) void pooled_sum_kernel(const T* __restrict__ a
   if (tid < C) {
     float s = 0.f;
     for (int k = 0; k < cpr; ++k) s += red[k * C + tid];
-    atomicAdd(&pooled[b * C + tid], s);
+    pooled[((size_t)blockIdx.x * gridDim.y + b) * C + tid] = s;
   }
 }
 
 // gate[b][c] = sigmoid(W2 relu(W1 (pooled[b]/HW)));  hidden[b][j] kept for the backward.  One workgroup per sample.
-__global__ __launch_bounds__(128) void ca_gate_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
-                                                          const float* __restrict__ w2, float* __restrict__ gate, float* __restrict__ hidden,
-                                                          int HW, int C, int R) {
+__global__ __launch_bounds__(128) void ca_gate_mlp_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ pooled,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          float* __restrict__ gate, float* __restrict__ hidden, int HW, int C, int R) {
   __shared__ float m[128], hdn[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < C) m[tid] = pooled[b * C + tid] / (float)HW;
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
+  if (tid < C) {
+    float s = 0.f;
+    for (int x = 0; x < nparts; ++x) s += partial[((size_t)x * B + b) * C + tid];
+    pooled[b * C + tid] = s;
+    m[tid] = s / (float)HW;
+  }
   __syncthreads();
   if (tid < R) {
     float s = 0.f;
@@ -111,35 +117,48 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(const T* __restrict__ res
   }
 }
 
-// backward of the tiny MLP per sample: dgate_sum[b][c] = sum_hw g*res (given) -> dmean[b][c]; dW1, dW2 accumulated over the batch
-__global__ __launch_bounds__(128) void ca_gate_mlp_bwd_kernel(const float* __restrict__ dgsum, const float* __restrict__ gate,
+// backward of the tiny MLP: dgate_sum[b][c] = sum_hw g*res (per-slice partials, summed here in a fixed order) -> dmean[b][c];
+// dW1, dW2 accumulated over the batch by ONE workgroup looping over the samples (deterministic, nothing to zero)
+__global__ __launch_bounds__(128) void ca_gate_mlp_bwd_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ gate,
                                                               const float* __restrict__ hidden, const float* __restrict__ pooled,
                                                               const float* __restrict__ w1, const float* __restrict__ w2,
                                                               float* __restrict__ dmean, float* __restrict__ dw1, float* __restrict__ dw2,
-                                                              int HW, int C, int R) {
+                                                              int B, int HW, int C, int R) {
   __shared__ float dz[128], dh[32], m[128], hdn[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < C) {
-    const float gt = gate[b * C + tid];
-    dz[tid] = dgsum[b * C + tid] * gt * (1.f - gt);      // through the sigmoid
-    m[tid] = pooled[b * C + tid] / (float)HW;
-  }
-  if (tid < R) hdn[tid] = hidden[b * R + tid];
-  __syncthreads();
-  if (tid < R) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += w2[c * R + tid] * dz[c];
-    dh[tid] = hdn[tid] > 0.f ? s : 0.f;                  // through the ReLU
-  }
-  __syncthreads();
-  if (tid < C) {
-    float s = 0.f;
-    for (int j = 0; j < R; ++j) s += w1[j * C + tid] * dh[j];
-    dmean[b * C + tid] = s / (float)HW;                  // d loss / d res[b][hw][c] through the mean
-    for (int j = 0; j < R; ++j) {
-      atomicAdd(&dw2[tid * R + j], dz[tid] * hdn[j]);
-      atomicAdd(&dw1[j * C + tid], dh[j] * m[tid]);
+  const int tid = threadIdx.x;
+  float a1[32], a2[32];        // thread c: dw2[c][j] and dw1[j][c], j < R <= 32
+#pragma unroll
+  for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  for (int b = 0; b < B; ++b) {
+    __syncthreads();
+    if (tid < C) {
+      float dg = 0.f;
+      for (int x = 0; x < nparts; ++x) dg += partial[((size_t)x * B + b) * C + tid];
+      const float gt = gate[b * C + tid];
+      dz[tid] = dg * gt * (1.f - gt);      // through the sigmoid
+      m[tid] = pooled[b * C + tid] / (float)HW;
     }
+    if (tid < R) hdn[tid] = hidden[b * R + tid];
+    __syncthreads();
+    if (tid < R) {
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += w2[c * R + tid] * dz[c];
+      dh[tid] = hdn[tid] > 0.f ? s : 0.f;                  // through the ReLU
+    }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f;
+      for (int j = 0; j < R; ++j) s += w1[j * C + tid] * dh[j];
+      dmean[b * C + tid] = s / (float)HW;                  // d loss / d res[b][hw][c] through the mean
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        if (j < R) { a2[j] += dz[tid] * hdn[j]; a1[j] += dh[j] * m[tid]; }
+    }
+  }
+  if (tid < C) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < R) { dw2[tid * R + j] = a2[j]; dw1[j * C + tid] = a1[j]; }
   }
 }
 
@@ -283,19 +302,19 @@ extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void
   return 0;
 }
 
-// stats fp32 [B*C (pooled sums) | B*C (gate) | B*R (hidden)]: pooled must be ZEROED by the caller
+// stats fp32 [B*C (pooled sums) | B*C (gate) | B*R (hidden) | 64*B*C (per-slice partial sums)]: nothing to zero
 extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats, int B, int HW,
                                 int C, int R, dgtd_dtype dt, dgtd_stream s) {
   const int V = dt == DGTD_BF16 ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_fwd: unsupported sizes C=%d R=%d", C, R);
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
-  float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
+  float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C, *partial = hidden + (size_t)B * R;
   const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
-  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, pooled, HW, C);
-  else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, pooled, HW, C);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
+  else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_pooled_sum");
-  hipLaunchKernelGGL(ca_gate_mlp_kernel, dim3(B), dim3(128), 0, st, (const float*)pooled, w1, w2, gate, hidden, HW, C, R);
+  hipLaunchKernelGGL(ca_gate_mlp_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, pooled, w1, w2, gate, hidden, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp");
   const int64_t rows = (int64_t)B * HW;
   if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)x, (const float*)gate, (bf16_t*)out, rows, HW, C);
@@ -304,7 +323,7 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
   return 0;
 }
 
-// scratch fp32 [B*C (dgate sums, ZEROED by the caller) | B*C (dmean)]; dw1 [R,C], dw2 [C,R] ZEROED by the caller; d(out)/dx is the identity
+// scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero; d(out)/dx is the identity
 extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                                 float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
   const int V = dt == DGTD_BF16 ? 8 : 4;
@@ -312,12 +331,12 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
-  float *dgsum = scratch, *dmean = scratch + (size_t)B * C;
+  float *dmean = scratch, *partial = scratch + (size_t)B * C;
   const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
-  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, dgsum, HW, C);
-  else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, dgsum, HW, C);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
+  else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
-  hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)dgsum, gate, hidden, pooled, w1, w2, dmean, dw1, dw2, HW, C, R);
+  hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(1), dim3(128), 0, st, (const float*)partial, gx, gate, hidden, pooled, w1, w2, dmean, dw1, dw2, B, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp_bwd");
   const int64_t rows = (int64_t)B * HW;
   if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C);

@@ -479,7 +479,7 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
     TORCH_CHECK(res.is_cuda(), "dgtd ca_gate runs on the HIP device");
     const int64_t B = res.size(0), C = res.size(1), HW = res.size(2) * res.size(3), R = w1.size(0);
     Tensor w1f = f32(w1.reshape({R, C})), w2f = f32(w2.reshape({C, R}));
-    Tensor stats = at::zeros({2 * B * C + B * R}, res.options().dtype(at::kFloat));
+    Tensor stats = at::empty({2 * B * C + B * R + 64 * B * C}, res.options().dtype(at::kFloat));
     Tensor out = at::empty_like(res);
     check(dgtd_ca_gate_fwd(res.data_ptr(), x.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), out.data_ptr(), stats.data_ptr<float>(),
                            (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_fwd");
@@ -493,7 +493,7 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
     const int64_t B = res.size(0), C = res.size(1), HW = res.size(2) * res.size(3), R = w1f.size(0);
     Tensor g = (gr[0].scalar_type() == res.scalar_type() ? gr[0] : gr[0].to(res.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dres = at::empty_like(res);
-    Tensor small = at::zeros({2 * R * C + 2 * B * C}, res.options().dtype(at::kFloat));
+    Tensor small = at::empty({2 * R * C + B * C + 64 * B * C}, res.options().dtype(at::kFloat));
     float* sp = small.data_ptr<float>();
     check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(),
                            sp, sp + R * C, sp + 2 * R * C, (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_bwd");

@@ -72,7 +72,7 @@ class _CAGateFn(Function):
         R = w1.shape[0]
         w1f = w1.detach().reshape(R, C).float().contiguous()
         w2f = w2.detach().reshape(C, R).float().contiguous()
-        stats = torch.zeros(2 * B * C + B * R, dtype=torch.float32, device=res.device)
+        stats = torch.empty(2 * B * C + B * R + 64 * B * C, dtype=torch.float32, device=res.device)
         out = torch.empty_like(res)
         L.call("dgtd_ca_gate_fwd", L.ptr(res), L.ptr(x), L.ptr(w1f), L.ptr(w2f), L.ptr(out), L.ptr(stats), B, H * W, C, R,
                L.dtype_code(res), L.stream_ptr(), algo=("hbm", 4 * res.element_size() * res.numel()),
@@ -90,7 +90,7 @@ class _CAGateFn(Function):
         R = w1f.shape[0]
         g = _nhwc(g if g.dtype == res.dtype else g.to(res.dtype))
         dres = torch.empty_like(res)
-        small = torch.zeros(2 * R * C + 2 * B * C, dtype=torch.float32, device=res.device)
+        small = torch.empty(2 * R * C + B * C + 64 * B * C, dtype=torch.float32, device=res.device)
         dw1, dw2, scratch = small[:R * C], small[R * C:2 * R * C], small[2 * R * C:]
         L.call("dgtd_ca_gate_bwd", L.ptr(g), L.ptr(res), L.ptr(w1f), L.ptr(w2f), L.ptr(stats), L.ptr(dres), dw1.data_ptr(),
                dw2.data_ptr(), scratch.data_ptr(), B, H * W, C, R, L.dtype_code(res), L.stream_ptr(),

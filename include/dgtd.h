@@ -148,10 +148,11 @@ int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float
                    dgtd_dtype dt, dgtd_stream s);
 /* out = res * sigmoid(W2 relu(W1 mean_hw(res))) + x : CALayer.forward (cod.py:428-431) plus the residual of CAB.forward
  * (cod.py:449-451).  res, x, out [B,HW,C]; w1 fp32 [R,C], w2 fp32 [C,R] (the bias-free 1x1 convs of cod.py:421-425);
- * C <= 128, R <= 32.  stats fp32 [2*B*C + B*R] = { pooled sums (ZEROED by the caller) | gate | hidden }, kept for the backward. */
+ * C <= 128, R <= 32.  stats fp32 [2*B*C + B*R + 64*B*C] = { pooled sums | gate | hidden | per-slice partial sums }: the first three
+ * are kept for the backward; nothing has to be zeroed (fixed-order sums, deterministic).                                          */
 int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats,
                      int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
-/* dres [B,HW,C] overwritten (d out / d x is the identity); dw1 [R,C], dw2 [C,R] and scratch fp32 [2*B*C] ZEROED by the caller. */
+/* dres [B,HW,C], dw1 [R,C], dw2 [C,R] overwritten (d out / d x is the identity); scratch fp32 [B*C + 64*B*C]; nothing to zero.  */
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 

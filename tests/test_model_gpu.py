@@ -243,3 +243,69 @@ def test_flat_adamw_matches_torch_adamw():
     sd = o1.state_dict()
     o1.load_state_dict(sd)
     assert o1.steps == 4
+
+
+def test_config1_256_eval_vs_reference_golden(dgtd):
+    """BASELINE.json configs[0] (256x256, batch 2, forward + loss): the HIP model in fp32 against the REFERENCE's own outputs
+    committed in tests/golden/model256.npz (loss scalar, strided samples and checksums of the logit map and of x_hp)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "model256.npz"))
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    filler.fill_module(net)
+    net = net.cuda().eval()
+    x, d, l = filler.synthetic_batch(2, 256)
+    with torch.no_grad():
+        x_hp, P1, P2 = net.hitnet(x.cuda(), d.cuda())
+        loss = net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"]
+    assert abs(loss.item() - float(g["eval.loss"])) <= LOGIT_TOL
+    logit = (P1[-1] + P2).double().flatten().cpu()
+    samples = logit[::int(g["eval.logit.step"])].float().numpy()
+    assert np.abs(samples - g["eval.logit.samples"]).max() <= LOGIT_TOL
+    assert abs(logit.sum().item() - float(g["eval.logit.sum"])) <= LOGIT_TOL * logit.numel() * 0.05     # mean error well inside the budget
+    xs = x_hp.double().flatten().cpu()[::int(g["eval.x_hp.step"])].float().numpy()
+    np.testing.assert_allclose(xs, g["eval.x_hp.samples"], rtol=1e-4, atol=1e-5)
+
+
+def test_config2_full_size_properties(dgtd):
+    """BASELINE.json configs[1] (512x512, batch 8): the CPU oracle needs ~47 s per step at this size, so parity is checked through
+    size-independent properties of the path: (i) eval outputs are reproducible (bit-identical reruns once MIOpen is restricted to
+    deterministic algorithms; its default fp32 strided-conv forward uses split-K atomics), (ii) samples are independent
+    in eval mode (no cross-sample op: BatchNorm uses running statistics), i.e. row i of the batch-8 result equals the batch-1 result
+    of sample i within fp32 GEMM re-tiling noise, (iii) the batch-8 loss is the mean of the per-sample cal_loss terms, (iv) one bf16
+    training step at full size yields a finite loss and finite, non-zero gradients in every trunk."""
+    S, B = 512, 8
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    filler.fill_module(net)
+    net = net.cuda().eval()
+    x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=11))
+    old_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        with torch.no_grad():
+            _, P1, P2 = net.hitnet(x, d)
+            _, Q1, Q2 = net.hitnet(x, d)
+    finally:
+        torch.backends.cudnn.deterministic = old_det
+    full = P1[-1] + P2
+    rerun = (full - (Q1[-1] + Q2)).abs().max().item()
+    assert rerun <= 1e-5, rerun
+    with torch.no_grad():
+        losses = []
+        for i in (0, 5):
+            _, R1, R2 = net.hitnet(x[i:i + 1], d[i:i + 1])
+            one = R1[-1] + R2
+            assert (one - full[i:i + 1]).abs().max().item() <= 1e-4
+            band = full[i:i + 1].abs() < 1e-4
+            assert torch.equal((one > 0)[~band], (full[i:i + 1] > 0)[~band])
+        batch_loss = net(None, x, l, d, mode="loss")["loss"].item()
+        for i in range(B):
+            losses.append(net(None, x[i:i + 1], l[i:i + 1], d[i:i + 1], mode="loss")["loss"].item())
+    # cal_loss is a mean over samples (cod.py:85) and the SSIM term a global mean of equally sized maps: the batch loss is the mean
+    assert abs(batch_loss - float(np.mean(losses))) <= 1e-3
+    tr = dgtd.nn.cod(compute_dtype=torch.bfloat16).cuda().train()
+    out = tr(None, x, l, d, mode="loss")["loss"]
+    out.backward()
+    assert torch.isfinite(out)
+    for name in ("hitnet.backbone.block1.0.attn.q.weight", "hitnet.backbone.prompt_encoder.encoder2.stages.2.13.pwconv1.weight",
+                 "hitnet.backbone.prompt_decoder.2.decoder.3.decoder.0.weight", "hitnet.decoder_level2.0.body.0.weight"):
+        gr = dict(tr.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name
