@@ -23,6 +23,7 @@ SIGNATURES = {
     "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
     "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
     "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
+    "dgtd_layernorm_bwd_add": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
     "dgtd_sra_attn_fwd": (_i, [_vp, _vp, _vp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
     "dgtd_sra_attn_bwd_workspace": (_i64, [_i, _i, _i]),
     "dgtd_sra_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _fp, _vp, _fp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ ws, int64_t rows, int C, int G) {
   typedef typename Vec16<T>::type VT;
   constexpr int V = Vec16<T>::N;
@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int i = 0; i < NPL; ++i) {
           int c = gl + i * G;
           if (c < cpr) {
-            VT o;
+            VT o, r;
+            if (dres) r = *reinterpret_cast<const VT*>(dres + row * C + (size_t)c * V);   // gradient of the residual branch that forks off x
 #pragma unroll
-            for (int j = 0; j < V; ++j) o[j] = (T)(rs[u] * (gv[u][i][j] - a - xv[u][i][j] * b));
+            for (int j = 0; j < V; ++j) o[j] = (T)(rs[u] * (gv[u][i][j] - a - xv[u][i][j] * b) + (dres ? (float)r[j] : 0.f));
             *reinterpret_cast<VT*>(dx + row * C + (size_t)c * V) = o;
           }
         }
@@ -257,14 +258,14 @@ int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y,
 
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                  float* dgamma, float* dbeta, void* ws, int64_t rows, int C, hipStream_t s) {
+                  float* dgamma, float* dbeta, void* ws, int64_t rows, int C, hipStream_t s, const void* dres = nullptr) {
   DGTD_REQUIRE(C % Vec16<T>::N == 0, "layernorm: C=%d must be a multiple of %d", C, Vec16<T>::N);
   LnGeom g = ln_geom<T>(C);
   DGTD_REQUIRE(g.npl <= LN_MAX_NPL, "layernorm: C=%d too large", C);
   DGTD_REQUIRE(rows > 0, "layernorm_bwd: rows must be > 0");
   int grid = (int)std::min<int64_t>(cdiv(rows, g.rows_per_block * 4), LN_BWD_MAX_GRID);
   size_t lds = (size_t)4 * 2 * C * sizeof(float);
-#define LN_BWD(NPL) hipLaunchKernelGGL((ln_bwd_kernel<T, NPL>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (float*)ws, rows, C, g.G)
+#define LN_BWD(NPL) hipLaunchKernelGGL((ln_bwd_kernel<T, NPL>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, (float*)ws, rows, C, g.G)
   switch (g.npl) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; default: LN_BWD(4); }
 #undef LN_BWD
   DGTD_CHECK_LAUNCH("layernorm_bwd");
@@ -280,6 +281,14 @@ extern "C" int dgtd_layernorm_fwd(const void* x, const float* gamma, const float
   if (dt == DGTD_F32) return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   if (dt == DGTD_BF16) return ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   DGTD_FAIL(2, "layernorm_fwd: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                      const void* dx_add, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
+                                      dgtd_dtype dt, dgtd_stream s) {
+  if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
+  if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
+  DGTD_FAIL(2, "layernorm_bwd_add: bad dtype %d", (int)dt);
 }
 
 extern "C" int64_t dgtd_layernorm_bwd_workspace(int C) { return (int64_t)LN_BWD_MAX_GRID * 2 * C * sizeof(float); }

@@ -58,6 +58,41 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
   }
 };
 
+// Pre-norm fork: returns (LayerNorm(x), x).  The second output is x itself, to be used for the skip connection: autograd then hands
+// BOTH gradients to this node and the backward adds them inside the LayerNorm backward kernel (dgtd_layernorm_bwd_add) instead
+// of a separate elementwise add per block.
+struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w, const Tensor& b, double eps) {
+    Tensor x = x_.contiguous();
+    on_device(x);
+    const int64_t C = x.size(-1), rows = x.numel() / C;
+    Tensor w32 = f32(w), b32 = f32(b);
+    Tensor y = at::empty_like(x);
+    Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
+    check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
+                             stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
+    ctx->save_for_backward({x, w32, stats});
+    return {y, x_};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w32 = saved[1], &stats = saved[2];
+    const int64_t C = x.size(-1), rows = x.numel() / C;
+    Tensor dres;
+    if (g[1].defined()) dres = (g[1].scalar_type() == x.scalar_type() ? g[1] : g[1].to(x.scalar_type())).contiguous();
+    if (!g[0].defined()) return {dres, undefined(), undefined(), undefined()};
+    Tensor dy = g[0].contiguous();
+    if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
+    Tensor dx = at::empty_like(x);
+    Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
+    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C)}, x.options().dtype(at::kByte));
+    check(dgtd_layernorm_bwd_add(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                                 dres.defined() ? dres.data_ptr() : nullptr, dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C,
+                                 ws.data_ptr(), rows, (int)C, code(x), stream()), "dgtd_layernorm_bwd_add");
+    return {dx, dgb[0], dgb[1], undefined()};
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ SRA attention
 struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& q_, const Tensor& kv_, int64_t heads, double scale) {
@@ -526,6 +561,10 @@ struct BilinearFn : public torch::autograd::Function<BilinearFn> {
 };
 
 Tensor layer_norm(const Tensor& x, const Tensor& w, const Tensor& b, double eps) { return LayerNormFn::apply(x, w, b, eps); }
+std::tuple<Tensor, Tensor> layer_norm_fork(const Tensor& x, const Tensor& w, const Tensor& b, double eps) {
+  auto r = LayerNormForkFn::apply(x, w, b, eps);
+  return {r[0], r[1]};
+}
 Tensor sra_attention(const Tensor& q, const Tensor& kv, int64_t heads, double scale) { return SraAttnFn::apply(q, kv, heads, scale); }
 Tensor dwconv_nhwc(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool gelu) { return DwConvFn::apply(x, w, b, gelu); }
 Tensor scale_residual(const Tensor& x, const Tensor& y, const c10::optional<Tensor>& s, const c10::optional<Tensor>& gamma) {
@@ -547,6 +586,7 @@ Tensor bilinear_resize(const Tensor& x, int64_t oh, int64_t ow, bool align) { re
 
 TORCH_LIBRARY(dgtd, m) {
   m.def("layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", &layer_norm);
+  m.def("layer_norm_fork(Tensor(a) x, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor(a))", &layer_norm_fork);
   m.def("sra_attention(Tensor q, Tensor kv, int heads, float scale) -> Tensor", &sra_attention);
   m.def("dwconv_nhwc(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> Tensor", &dwconv_nhwc);
   m.def("scale_residual(Tensor x, Tensor y, Tensor? s, Tensor? gamma) -> Tensor", &scale_residual);

@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -132,6 +132,10 @@ class LayerNorm(nn.Module):
             return y.permute(0, 3, 1, 2)
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def fork(self, x):
+        """(norm(x), x): the second value is for the skip connection of a pre-norm block (gradient add fused into the backward)."""
+        return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
+
 
 # ------------------------------------------------------------------------------------------------ PVTv2
 class OverlapPatchEmbed(nn.Module):
@@ -233,8 +237,10 @@ class Block(nn.Module):
 
     def forward(self, x, H, W):
         if _USE["fused_linear"] and x.is_cuda:   # projection / fc2 + DropPath + residual as one node (bias gradient fused in its backward)
-            x = ops.linear_residual(self.attn.core(self.norm1(x), H, W), *wb(self.attn.proj), x, self._scale(x))
-            return ops.linear_residual(self.mlp.hidden(self.norm2(x), H, W), *wb(self.mlp.fc2), x, self._scale(x))
+            v, xs = self.norm1.fork(x) if _USE["ln_fork"] else (self.norm1(x), x)
+            x = ops.linear_residual(self.attn.core(v, H, W), *wb(self.attn.proj), xs, self._scale(x))
+            v, xs = self.norm2.fork(x) if _USE["ln_fork"] else (self.norm2(x), x)
+            return ops.linear_residual(self.mlp.hidden(v, H, W), *wb(self.mlp.fc2), xs, self._scale(x))
         x = ops.scale_residual(x, self.attn(self.norm1(x), H, W), self._scale(x))   # x + DropPath(attn), one pass
         return ops.scale_residual(x, self.mlp(self.norm2(x), H, W), self._scale(x))
 

@@ -50,3 +50,12 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     if nat is not None and x.is_cuda:
         return nat.layer_norm(x, weight, bias, eps)
     return _LayerNormFn.apply(x.contiguous(), weight, bias, eps)
+
+
+def layer_norm_fork(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """(LayerNorm(x), x) for pre-norm residual blocks: use the second value for the skip connection.  With the C++ bindings both
+    gradients arrive at one node and are added inside the LayerNorm backward kernel (dgtd_layernorm_bwd_add)."""
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.layer_norm_fork(x, weight, bias, eps)
+    return _LayerNormFn.apply(x.contiguous(), weight, bias, eps), x

@@ -44,6 +44,12 @@ int dgtd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        const float* rstd, void* dx, float* dgamma, float* dbeta, void* workspace,
                        int64_t rows, int C, dgtd_dtype dt, dgtd_stream s);
 
+/* Same, with the gradient of a residual branch that forks off x added in the same pass: dx = LayerNorm'(dy) + dx_add (dx_add may be
+ * NULL).  Pre-norm residual blocks (x feeds the norm AND the skip connection, cod.py:958-959) otherwise pay a separate add.    */
+int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                           const void* dx_add, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows,
+                           int C, dgtd_dtype dt, dgtd_stream s);
+
 /* ---- Spatial-reduction multi-head attention core: softmax(Q K^T * scale) V, head_dim = 64 -----
  * replaces twig/model/cod.py:913-917 (the q/kv/proj Linears stay GEMM calls).
  * q   [B, N,   heads*64]      = output of Attention.q   (cod.py:902) — head h in cols [64h, 64h+64)

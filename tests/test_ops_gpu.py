@@ -399,3 +399,29 @@ def test_linear_residual_fused_backward(dgtd, rows, K, N, dtype, with_s, with_g)
     torch.testing.assert_close(got[1].float(), rg[1], atol=tol, rtol=tol)
     for a_, r_ in zip(got[2:], rg[2:]):
         torch.testing.assert_close(a_.float(), r_, atol=tol * math.sqrt(rows), rtol=tol)
+
+
+@pytest.mark.parametrize("C", [64, 320, 512])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fork_adds_skip_gradient(dgtd, C, dtype):
+    """(LN(x), x): the gradient of the skip branch is added inside the LayerNorm backward; result == autograd's separate add."""
+    rows = 1000
+    x = _rand(rows, C, seed=1, dtype=dtype)
+    w = (1 + 0.1 * _rand(C, seed=2)).requires_grad_()
+    b = (0.1 * _rand(C, seed=3)).requires_grad_()
+    g1, g2 = _rand(rows, C, seed=4, dtype=dtype), _rand(rows, C, seed=5, dtype=dtype)
+    xr = x.float().requires_grad_()
+    ref = F.layer_norm(xr, (C,), w, b, 1e-6)
+    gx, gw, gb = torch.autograd.grad([ref, xr * 1.0], (xr, w, b), [g1.float(), g2.float()])
+    xs = x.clone().requires_grad_()
+    y, skip = dgtd.ops.layer_norm_fork(xs, w, b, 1e-6)
+    hx, hw, hb = torch.autograd.grad([y, skip * 1.0], (xs, w, b), [g1, g2])
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
+    torch.testing.assert_close(hw, gw, atol=(2e-4 if dtype == torch.float32 else 5e-2) * math.sqrt(rows), rtol=5e-2)
+    # only the norm output used: the skip gradient is absent
+    y2, _ = dgtd.ops.layer_norm_fork(xs, w, b, 1e-6)
+    h2, = torch.autograd.grad(y2, xs, g1)
+    g2x, = torch.autograd.grad(F.layer_norm(xr, (C,), w, b, 1e-6), xr, g1.float())
+    torch.testing.assert_close(h2.float(), g2x, atol=tol, rtol=tol)
