@@ -117,58 +117,60 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(const T* __restrict__ res
   }
 }
 
-// backward of the tiny MLP: dgate_sum[b][c] = sum_hw g*res (per-slice partials, summed here in a fixed order) -> dmean[b][c];
-// dW1, dW2 accumulated over the batch by ONE workgroup looping over the samples (deterministic, nothing to zero)
+// backward of the tiny MLP, one workgroup per sample: dgate_sum[b][c] = sum_hw g*res (per-slice partials, summed here in a fixed
+// order) -> dmean[b][c]; the per-sample outer products dz x hidden and dh x mean go to dwp[b][2*R*C] and are summed over the batch
+// in a fixed order by workgroup 0 of ca_apply_bwd_kernel (deterministic, nothing to zero, no extra launch)
 __global__ __launch_bounds__(128) void ca_gate_mlp_bwd_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ gate,
                                                               const float* __restrict__ hidden, const float* __restrict__ pooled,
                                                               const float* __restrict__ w1, const float* __restrict__ w2,
-                                                              float* __restrict__ dmean, float* __restrict__ dw1, float* __restrict__ dw2,
-                                                              int B, int HW, int C, int R) {
+                                                              float* __restrict__ dmean, float* __restrict__ dwp, int HW, int C, int R) {
   __shared__ float dz[128], dh[32], m[128], hdn[32];
-  const int tid = threadIdx.x;
-  float a1[32], a2[32];        // thread c: dw2[c][j] and dw1[j][c], j < R <= 32
-#pragma unroll
-  for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
-  for (int b = 0; b < B; ++b) {
-    __syncthreads();
-    if (tid < C) {
-      float dg = 0.f;
-      for (int x = 0; x < nparts; ++x) dg += partial[((size_t)x * B + b) * C + tid];
-      const float gt = gate[b * C + tid];
-      dz[tid] = dg * gt * (1.f - gt);      // through the sigmoid
-      m[tid] = pooled[b * C + tid] / (float)HW;
-    }
-    if (tid < R) hdn[tid] = hidden[b * R + tid];
-    __syncthreads();
-    if (tid < R) {
-      float s = 0.f;
-      for (int c = 0; c < C; ++c) s += w2[c * R + tid] * dz[c];
-      dh[tid] = hdn[tid] > 0.f ? s : 0.f;                  // through the ReLU
-    }
-    __syncthreads();
-    if (tid < C) {
-      float s = 0.f;
-      for (int j = 0; j < R; ++j) s += w1[j * C + tid] * dh[j];
-      dmean[b * C + tid] = s / (float)HW;                  // d loss / d res[b][hw][c] through the mean
-#pragma unroll
-      for (int j = 0; j < 32; ++j)
-        if (j < R) { a2[j] += dz[tid] * hdn[j]; a1[j] += dh[j] * m[tid]; }
-    }
-  }
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
   if (tid < C) {
-#pragma unroll
-    for (int j = 0; j < 32; ++j)
-      if (j < R) { dw2[tid * R + j] = a2[j]; dw1[j * C + tid] = a1[j]; }
+    float dg0 = 0.f, dg1 = 0.f;
+    int x = 0;
+    for (; x + 1 < nparts; x += 2) { dg0 += partial[((size_t)x * B + b) * C + tid]; dg1 += partial[((size_t)(x + 1) * B + b) * C + tid]; }
+    if (x < nparts) dg0 += partial[((size_t)x * B + b) * C + tid];
+    const float gt = gate[b * C + tid];
+    dz[tid] = (dg0 + dg1) * gt * (1.f - gt);      // through the sigmoid
+    m[tid] = pooled[b * C + tid] / (float)HW;
+  }
+  if (tid < R) hdn[tid] = hidden[b * R + tid];
+  __syncthreads();
+  if (tid < R) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += w2[c * R + tid] * dz[c];
+    dh[tid] = hdn[tid] > 0.f ? s : 0.f;                  // through the ReLU
+  }
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int j = 0; j < R; ++j) s += w1[j * C + tid] * dh[j];
+    dmean[b * C + tid] = s / (float)HW;                  // d loss / d res[b][hw][c] through the mean
+    float* o = dwp + (size_t)b * 2 * R * C;              // [dw1 (R x C) | dw2 (C x R)] of this sample
+    for (int j = 0; j < R; ++j) {
+      o[j * C + tid] = dh[j] * m[tid];
+      o[R * C + tid * R + j] = dz[tid] * hdn[j];
+    }
   }
 }
 
 // dres = g * gate[b][c] + dmean[b][c]
 template <typename T>
 __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const T* __restrict__ g, const float* __restrict__ gate, const float* __restrict__ dmean,
-                                                           T* __restrict__ dres, int64_t rows, int HW, int C) {
+                                                           T* __restrict__ dres, int64_t rows, int HW, int C, const float* __restrict__ dwp,
+                                                           float* __restrict__ dw1, float* __restrict__ dw2, int B, int R) {
   typedef typename Vec16<T>::type VT;
   constexpr int V = Vec16<T>::N;
   const int CV = C / V;
+  if (blockIdx.x == 0) {      // dw1 [R,C] | dw2 [C,R] = sum over the samples of the per-sample outer products (fixed order)
+    const int n = 2 * R * C;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dwp[(size_t)b * n + i];
+      if (i < R * C) dw1[i] = s; else dw2[i - R * C] = s;
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * CV; i += (int64_t)gridDim.x * 256) {
     const int cv = (int)(i % CV);
     const int b = (int)((i / CV) / HW);
@@ -323,7 +325,7 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
   return 0;
 }
 
-// scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero; d(out)/dx is the identity
+// scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums) | B*2*R*C (per-sample dw)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero
 extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                                 float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
   const int V = dt == DGTD_BF16 ? 8 : 4;
@@ -331,16 +333,16 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
-  float *dmean = scratch, *partial = scratch + (size_t)B * C;
+  float *dmean = scratch, *partial = scratch + (size_t)B * C, *dwp = partial + (size_t)64 * B * C;
   const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
   if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
-  hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(1), dim3(128), 0, st, (const float*)partial, gx, gate, hidden, pooled, w1, w2, dmean, dw1, dw2, B, HW, C, R);
+  hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, gate, hidden, pooled, w1, w2, dmean, dwp, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp_bwd");
   const int64_t rows = (int64_t)B * HW;
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C);
-  else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C);
+  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
+  else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
   DGTD_CHECK_LAUNCH("ca_apply_bwd");
   return 0;
 }

@@ -528,7 +528,7 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
     const int64_t B = res.size(0), C = res.size(1), HW = res.size(2) * res.size(3), R = w1f.size(0);
     Tensor g = (gr[0].scalar_type() == res.scalar_type() ? gr[0] : gr[0].to(res.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dres = at::empty_like(res);
-    Tensor small = at::empty({2 * R * C + B * C + 64 * B * C}, res.options().dtype(at::kFloat));
+    Tensor small = at::empty({2 * R * C + B * C + 64 * B * C + B * 2 * R * C}, res.options().dtype(at::kFloat));
     float* sp = small.data_ptr<float>();
     check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(),
                            sp, sp + R * C, sp + 2 * R * C, (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_bwd");

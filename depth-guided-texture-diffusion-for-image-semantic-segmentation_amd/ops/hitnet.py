@@ -90,7 +90,7 @@ class _CAGateFn(Function):
         R = w1f.shape[0]
         g = _nhwc(g if g.dtype == res.dtype else g.to(res.dtype))
         dres = torch.empty_like(res)
-        small = torch.empty(2 * R * C + B * C + 64 * B * C, dtype=torch.float32, device=res.device)
+        small = torch.empty(2 * R * C + B * C + 64 * B * C + B * 2 * R * C, dtype=torch.float32, device=res.device)
         dw1, dw2, scratch = small[:R * C], small[R * C:2 * R * C], small[2 * R * C:]
         L.call("dgtd_ca_gate_bwd", L.ptr(g), L.ptr(res), L.ptr(w1f), L.ptr(w2f), L.ptr(stats), L.ptr(dres), dw1.data_ptr(),
                dw2.data_ptr(), scratch.data_ptr(), B, H * W, C, R, L.dtype_code(res), L.stream_ptr(),

@@ -158,7 +158,7 @@ int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float
  * are kept for the backward; nothing has to be zeroed (fixed-order sums, deterministic).                                          */
 int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats,
                      int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
-/* dres [B,HW,C], dw1 [R,C], dw2 [C,R] overwritten (d out / d x is the identity); scratch fp32 [B*C + 64*B*C]; nothing to zero.  */
+/* dres [B,HW,C], dw1 [R,C], dw2 [C,R] overwritten (d out / d x is the identity); scratch fp32 [B*C + 64*B*C + B*2*R*C]; nothing to zero. */
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 

@@ -3,7 +3,7 @@
 
     python tools/trace_summary.py gpurun_out/prof/.../*_kernel_trace.csv [--top 40] > profiles/rNN_step_kernels.txt
 
-Steps are delimited by the fused-AdamW kernels (multi_tensor_apply); the LAST full step is reported so
+Steps are delimited by the AdamW kernels (dgtd adamw_flat_kernel or torch's multi_tensor_apply); the LAST full step is reported so
 MIOpen's first-step solver search and allocator warm-up are excluded."""
 import collections
 import csv
@@ -20,7 +20,7 @@ def category(n: str) -> str:
         return "dgtd HIP kernels"
     if "reduce_kernel" in n:
         return "torch reductions"
-    if "FusedOptim" in n or "multi_tensor" in n:
+    if "FusedOptim" in n or "multi_tensor" in n or "adamw_flat" in n:
         return "AdamW / multi-tensor"
     if "fill" in n.lower():
         return "fills / memsets"
@@ -42,7 +42,7 @@ def main():
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
+    opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"] or "adamw_flat_kernel" in r["Kernel_Name"]]
     groups, prev = [], None
     for i in opt:
         if prev is None or i - prev > 50:
