@@ -79,8 +79,11 @@ __global__ __launch_bounds__(128) void ca_gate_mlp_kernel(const float* __restric
   __shared__ float m[128], hdn[32];
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
   if (tid < C) {
-    float s = 0.f;
-    for (int x = 0; x < nparts; ++x) s += partial[((size_t)x * B + b) * C + tid];
+    float s0 = 0.f, s1 = 0.f;
+    int x = 0;
+    for (; x + 1 < nparts; x += 2) { s0 += partial[((size_t)x * B + b) * C + tid]; s1 += partial[((size_t)(x + 1) * B + b) * C + tid]; }
+    if (x < nparts) s0 += partial[((size_t)x * B + b) * C + tid];
+    const float s = s0 + s1;
     pooled[b * C + tid] = s;
     m[tid] = s / (float)HW;
   }
@@ -312,7 +315,7 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C, *partial = hidden + (size_t)B * R;
-  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
   if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_pooled_sum");
@@ -334,7 +337,7 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   hipStream_t st = (hipStream_t)s;
   const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
   float *dmean = scratch, *partial = scratch + (size_t)B * C, *dwp = partial + (size_t)64 * B * C;
-  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
   if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
