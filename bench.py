@@ -68,6 +68,11 @@ def cpu_baseline(size: int, log=lambda m: None):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the result JSON: keep a private handle to it and point fd 1 at stderr so that library
+    # banners (RCCL prints "Hostname / Librccl path" on stdout when the first communicator is created) cannot get in front of it
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run shows where it is stuck
     t_start = time.perf_counter()
@@ -220,8 +225,8 @@ def main():
             log("timing the CPU oracle on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(args.size, log)
         faulthandler.cancel_dump_traceback_later()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=result_out, flush=True)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

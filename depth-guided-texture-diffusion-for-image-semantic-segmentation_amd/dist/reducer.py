@@ -31,7 +31,8 @@ def init_process_group(backend: Optional[str] = None) -> tuple:
     """One process per GPU; rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1 and not dist.is_initialized():
+    # DGTD_FORCE_ALLREDUCE=1: rehearse the RCCL path (process group, side-stream all-reduce) with a single rank on a one-GPU box
+    if (world > 1 or os.environ.get("DGTD_FORCE_ALLREDUCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -96,7 +97,8 @@ class GradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._seal(cur, castable)
-        self.overlap = overlap and self.world > 1
+        self._force = os.environ.get("DGTD_FORCE_ALLREDUCE") == "1" and dist.is_initialized()
+        self.overlap = overlap and (self.world > 1 or self._force)
         self._cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self._cuda and self.overlap) else None
         self._works = []
@@ -213,17 +215,22 @@ class GradReducer:
         bucket["done"] = True
 
     def _launch(self, bucket) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         flat = bucket["flat"]
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests) has no AVG: scale, then sum
+        avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self._cuda and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                flat.div_(self.world)
-                w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if not avg:
+                    flat.div_(self.world)
+                w = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         else:
-            flat.div_(self.world)
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not avg:
+                flat.div_(self.world)
+            w = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self._works.append(w)
 
     def finish(self) -> None:
