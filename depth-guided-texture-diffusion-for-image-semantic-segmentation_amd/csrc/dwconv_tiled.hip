@@ -69,10 +69,13 @@ __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restri
   const int y0 = ty * TY, x0 = tx * TXW, c0 = cb * 128 + lane * 2;
   stage_tile<T, K>(tile, x, b, y0, x0, cb, H, W, C, tid);
   // all K*K taps of this lane's two channels, and the bias, stay in registers (loaded behind the tile: the staging registers are dead)
-  float w[K * K][2];
+  // the lane's two channels travel as float2 values: the multiply-adds compile to v_pk_fma_f32 (two FMAs per VALU instruction)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 w[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) { w[i][0] = wt[(size_t)i * C + c0]; w[i][1] = wt[(size_t)i * C + c0 + 1]; }
-  const float b0 = bias ? bias[c0] : 0.f, b1 = bias ? bias[c0 + 1] : 0.f;
+  f2 bv;
+  bv[0] = bias ? bias[c0] : 0.f; bv[1] = bias ? bias[c0 + 1] : 0.f;
   __syncthreads();
   const int oy = y0 + wave;                       // this wave's output row
   if (oy >= H) return;
@@ -80,12 +83,12 @@ __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restri
   for (int s = 0; s < TXW / TXS; ++s) {
     const int sx = s * TXS;
     if (x0 + sx >= W) break;
-    float acc[TXS][2];
+    f2 acc[TXS];
 #pragma unroll
-    for (int i = 0; i < TXS; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
+    for (int i = 0; i < TXS; ++i) acc[i] = bv;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      float in[TXS + K - 1][2];
+      f2 in[TXS + K - 1];
       const T* row = tile + ((size_t)(wave + ky) * RW + sx) * 128 + lane * 2;
 #pragma unroll
       for (int i = 0; i < TXS + K - 1; ++i) {
@@ -95,10 +98,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restri
 #pragma unroll
       for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-        for (int i = 0; i < TXS; ++i) {
-          acc[i][0] += in[i + kx][0] * w[ky * K + kx][0];
-          acc[i][1] += in[i + kx][1] * w[ky * K + kx][1];
-        }
+        for (int i = 0; i < TXS; ++i) acc[i] = __builtin_elementwise_fma(in[i + kx], w[ky * K + kx], acc[i]);
     }
 #pragma unroll
     for (int i = 0; i < TXS; ++i) {
