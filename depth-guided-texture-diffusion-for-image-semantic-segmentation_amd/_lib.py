@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgtd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F64 = 0, 1, 2
 _vp, _fp, _i, _i64, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); kept in lock-step with include/dgtd.h (tests/test_abi.py parses the header)
@@ -48,6 +48,8 @@ SIGNATURES = {
     "dgtd_diffuse_tail_bwd_workspace": (_i64, [_i]),
     "dgtd_diffuse_tail_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_ms_deform_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_prelu_fwd": (_i, [_vp, _fp, _vp, _i64, _i, _vp]),
     "dgtd_prelu_bwd": (_i, [_vp, _vp, _fp, _vp, _fp, _i64, _i, _vp]),
     "dgtd_ca_gate_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-typedef enum { DGTD_F32 = 0, DGTD_BF16 = 1 } dgtd_dtype;
+typedef enum { DGTD_F32 = 0, DGTD_BF16 = 1, DGTD_F64 = 2 /* ms_deform_attn only */ } dgtd_dtype;
 typedef void* dgtd_stream; /* hipStream_t */
 
 int dgtd_version(void);
@@ -194,6 +194,21 @@ int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw
  * p *= 1-lr*wd; m += (1-b1)(g-m); v = b2 v + (1-b2) g*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); w = bf16(p).               */
 int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float bias_correction1, float bias_correction2, dgtd_stream s);
+
+/* ---- Multi-scale deformable attention sampling: the reference's own native op (twig/ops) ------------------------
+ * replaces MSDA.ms_deform_attn_forward / ms_deform_attn_backward (twig/ops/src/ms_deform_attn.h:20-60, bound at
+ * twig/ops/functions/ms_deform_attn_func.py:24-46); semantics = ms_deform_attn_core_pytorch (ms_deform_attn_func.py:49-71).
+ * value [N,S,M,D]; spatial_shapes int64 [L,2] = (H_l, W_l); level_start_index int64 [L]; sampling_loc [N,Lq,M,L,P,2] = (x, y) in
+ * [0,1]; attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D].  dt = DGTD_F32 or DGTD_F64 (the reference casts half inputs to float32,
+ * ms_deform_attn_func.py:21).  The reference's im2col_step only batches its host loop and has no counterpart here.             */
+int dgtd_ms_deform_attn_fwd(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M, int D, int L,
+                            int Lq, int P, dgtd_dtype dt, dgtd_stream s);
+/* grad_value [N,S,M,D] must be ZEROED by the caller (atomics); grad_sampling_loc and grad_attn_weight are overwritten.           */
+int dgtd_ms_deform_attn_bwd(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const void* sampling_loc, const void* attn_weight, const void* grad_out, void* grad_value,
+                            void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                            dgtd_dtype dt, dgtd_stream s);
 
 #ifdef __cplusplus
 }

@@ -160,9 +160,40 @@ def gen_model(S: int, B: int, with_grads: bool) -> dict:
     return out
 
 
+def gen_msda() -> dict:
+    """The reference's own ms_deform_attn_core_pytorch (twig/ops/functions/ms_deform_attn_func.py:49-71), imported with an empty stub
+    for the compiled MultiScaleDeformableAttention module, on the deterministic cases of oracle/ms_deform_attn_cpu.py."""
+    import importlib.util
+    import types
+    from . import ms_deform_attn_cpu as mc
+    sys.modules.setdefault("MultiScaleDeformableAttention", types.ModuleType("MultiScaleDeformableAttention"))
+    path = os.path.join(ref_loader.REFERENCE_ROOT, "twig", "ops", "functions", "ms_deform_attn_func.py")
+    spec = importlib.util.spec_from_file_location("ref_msda_func", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    out = {}
+    for name, (N, M, D, Lq, shapes, P) in mc.CASES.items():
+        value, shp, loc, attn, grad = mc.case_inputs(name, N, M, D, Lq, shapes, P)
+        value.requires_grad_(); loc.requires_grad_(); attn.requires_grad_()
+        y = mod.ms_deform_attn_core_pytorch(value, shp, loc, attn)
+        gv, gl, ga = torch.autograd.grad(y, (value, loc, attn), grad)
+        out[f"{name}.out"] = y.detach().numpy()
+        if gv.numel() <= 1 << 16:
+            out[f"{name}.grad_value"] = gv.numpy()
+        else:
+            for k, v in digest(gv).items():
+                out[f"{name}.grad_value.{k}"] = v
+        out[f"{name}.grad_loc"] = gl.numpy()
+        out[f"{name}.grad_attn"] = ga.numpy()
+    return out
+
+
 def main(argv):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    want = set(argv) or {"modules", "model64", "model256"}
+    want = set(argv) or {"modules", "model64", "model256", "msda"}
+    if "msda" in want:
+        np.savez_compressed(os.path.join(GOLDEN_DIR, "msda.npz"), **gen_msda())
     if "modules" in want:
         np.savez_compressed(os.path.join(GOLDEN_DIR, "modules.npz"), **gen_modules(ref_loader.load_reference_cod()))
     if "model64" in want:

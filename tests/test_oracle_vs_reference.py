@@ -34,3 +34,22 @@ def test_keys_forward_backward_bit_exact():
         a, b = ref.hitnet(x, d), mine.hitnet(x, d)
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     assert all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
+
+
+def test_msda_restatement_vs_live_reference_function():
+    """oracle/ms_deform_attn_cpu.py against the reference's ms_deform_attn_core_pytorch (twig/ops/functions/ms_deform_attn_func.py:49-71),
+    imported with an empty stub for the compiled MultiScaleDeformableAttention module."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    from oracle import ms_deform_attn_cpu as mc
+    sys.modules.setdefault("MultiScaleDeformableAttention", types.ModuleType("MultiScaleDeformableAttention"))
+    path = os.path.join(ref_loader.REFERENCE_ROOT, "twig", "ops", "functions", "ms_deform_attn_func.py")
+    spec = importlib.util.spec_from_file_location("ref_msda_func_live", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    for name, (N, M, D, Lq, shapes, P) in mc.CASES.items():
+        value, shp, loc, attn, _ = mc.case_inputs(name, N, M, D, Lq, shapes, P)
+        assert torch.equal(mc.ms_deform_attn(value, shp, loc, attn), mod.ms_deform_attn_core_pytorch(value, shp, loc, attn)), name
