@@ -50,6 +50,8 @@ SIGNATURES = {
     "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ms_deform_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_preprocess_workspace": (_i64, [_i, _i, _i, _i]),
+    "dgtd_preprocess": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_prelu_fwd": (_i, [_vp, _fp, _vp, _i64, _i, _vp]),
     "dgtd_prelu_bwd": (_i, [_vp, _vp, _fp, _vp, _fp, _i64, _i, _vp]),
     "dgtd_ca_gate_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),

@@ -210,6 +210,16 @@ int dgtd_ms_deform_attn_bwd(const void* value, const int64_t* spatial_shapes, co
                             void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                             dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Input pipeline of one sample on the device --------------------------------------------------------
+ * replaces the per-sample transforms of twig/dataset/sod_train.py:31-54 (applied at :65-83): RandomHorizontalFlip (the caller
+ * draws the coin) -> Resize((S,S)) = Pillow BILINEAR with antialiasing (requirements.txt:92, via torchvision Resize :148) ->
+ * ToTensor -> optional Normalize.  img_u8 [Hin,Win,C] uint8 on the device (C = 3 RGB or 1 for GT / depth); out [C,S,S] in out_dt.
+ * mean_host / std_host: HOST arrays of C floats or both NULL (no normalisation).  Bit-exact against Pillow + float32 ToTensor /
+ * Normalize.  workspace: dgtd_preprocess_workspace(...) bytes on the device (uint8 intermediate + coefficient tables).           */
+int64_t dgtd_preprocess_workspace(int Hin, int Win, int C, int S);
+int dgtd_preprocess(const void* img_u8, void* out, const float* mean_host, const float* std_host, void* workspace, int Hin,
+                    int Win, int C, int S, int flip, dgtd_dtype out_dt, dgtd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

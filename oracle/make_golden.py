@@ -189,8 +189,27 @@ def gen_msda() -> dict:
     return out
 
 
+PREPROCESS_CASES = [("rgb_down", 97, 131, 3, 64), ("rgb_up", 20, 30, 3, 48), ("gray_mixed", 50, 33, 1, 40), ("rgb_same_w", 90, 64, 3, 64)]
+
+
+def gen_preprocess() -> dict:
+    """Real Pillow (Image.resize BILINEAR, what torchvision's Resize calls on PIL images, sod_train.py:33) on deterministic uint8
+    images; ToTensor / Normalize are float32 one-liners restated in oracle/preprocess_cpu.py."""
+    from PIL import Image
+    out = {}
+    for name, h, w, c, s in PREPROCESS_CASES:
+        x = (filler.uniform("preprocess/" + name, h * w * c) * 256).astype(np.uint8).reshape(h, w, c)
+        xi = x[:, :, 0] if c == 1 else x
+        out[name + ".in"] = x
+        out[name + ".resized"] = np.asarray(Image.fromarray(xi).resize((s, s), Image.BILINEAR))
+        out[name + ".resized_flip"] = np.asarray(Image.fromarray(np.ascontiguousarray(xi[:, ::-1])).resize((s, s), Image.BILINEAR))
+    return out
+
+
 def main(argv):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if not argv or "preprocess" in argv:
+        np.savez_compressed(os.path.join(GOLDEN_DIR, "preprocess.npz"), **gen_preprocess())
     want = set(argv) or {"modules", "model64", "model256", "msda"}
     if "msda" in want:
         np.savez_compressed(os.path.join(GOLDEN_DIR, "msda.npz"), **gen_msda())
