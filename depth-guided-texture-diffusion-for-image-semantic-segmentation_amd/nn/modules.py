@@ -414,7 +414,10 @@ class ShapePropDecoder(nn.Module):
         Hin = h.shape[-2]
         s_ = Hin // H
         if s_ == 1:
-            y = F.conv2d(h, w, b, padding=1)
+            if _USE["conv3x3"] and w.dtype == h.dtype and ops.conv3x3_ops.supported(h, w.shape[1], w.shape[0], Hin, h.shape[-1]):
+                y = ops.conv3x3(h, w, b)                # stage-1 prompts (24 -> 64 at S/4): same kernel as the trunk layers
+            else:
+                y = F.conv2d(h, w, b, padding=1)
         elif s_ in (2, 4, 8) and Hin == H * s_ and h.shape[-1] == W * s_:
             w4 = F.avg_pool2d(w, 2, stride=1, padding=1)   # mean of the four shifted 3x3 kernels (zero padded), one launch
             off = s_ // 2 - 2                      # first input row/col of the 4x4 window of output 0
@@ -535,6 +538,11 @@ class BasicConv2d(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        c = self.conv
+        w = wb(c)[0]
+        if (_USE["conv3x3"] and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+                and w.dtype == x.dtype and ops.conv3x3_ops.supported(x, c.in_channels, c.out_channels, x.shape[2], x.shape[3])):
+            return self.bn(ops.conv3x3(x, w))        # conv4 (96 -> 32 at S/8, cod.py:713): NHWC bf16 MFMA kernel
         return self.bn(self.conv(x))
 
 
