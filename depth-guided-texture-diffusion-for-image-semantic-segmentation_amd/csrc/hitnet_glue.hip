@@ -250,9 +250,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
     const int iw = (int)(r % Wi);
     r /= Wi;
     const int ih = (int)(r % Hi), b = (int)(r / Hi);
-    // conservative candidate ranges: outputs whose source coordinate can lie within (i-1, i+1)
-    const int oh_lo = max(0, (int)floorf(((float)ih - 1.f) * inv_h) - 1), oh_hi = min(Ho - 1, (int)ceilf(((float)ih + 1.f) * inv_h) + 1);
-    const int ow_lo = max(0, (int)floorf(((float)iw - 1.f) * inv_w) - 1), ow_hi = min(Wo - 1, (int)ceilf(((float)iw + 1.f) * inv_w) + 1);
+    // conservative candidate ranges: outputs whose source coordinate can lie within (i-1, i+1).  align_corners: src = scale*o, so
+    // o in ((i-1)/scale, (i+1)/scale); otherwise src = scale*(o+0.5)-0.5, so o in ((i-0.5)/scale-0.5, (i+1.5)/scale-0.5).  One
+    // range covers both (the exact tap weights below discard the extra candidates).
+    const int oh_lo = max(0, (int)floorf(((float)ih - 1.f) * inv_h) - 2), oh_hi = min(Ho - 1, (int)ceilf(((float)ih + 1.5f) * inv_h) + 1);
+    const int ow_lo = max(0, (int)floorf(((float)iw - 1.f) * inv_w) - 2), ow_hi = min(Wo - 1, (int)ceilf(((float)iw + 1.5f) * inv_w) + 1);
     float acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;

@@ -315,8 +315,16 @@ class ShapePropEncoder(nn.Module):
         for (t, h, w), conv in zip(outs, self.convs):  # 1x1 conv == GEMM on tokens, then bilinear to stride 4
             cw, cb = wb(conv)
             y = _tokens_to_nchw(ops.linear(t, cw.flatten(1), cb), h, w)
-            taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
-        return self.fusion_conv(torch.cat(taps, dim=1))
+            if (h, w) == size:
+                taps.append(y)                                   # bilinear resize to the same size is the identity
+            elif _USE["bilinear"] and y.is_cuda and y.shape[1] % (16 // y.element_size()) == 0:
+                taps.append(ops.bilinear_resize(y, size[0], size[1], False))
+            else:
+                taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
+        cat = torch.cat(taps, dim=1)
+        fw, fb = wb(self.fusion_conv)                            # 1x1 conv == GEMM on tokens
+        Bc, Cc, Hc, Wc = cat.shape
+        return _tokens_to_nchw(ops.linear(_nchw_to_tokens(cat), fw.flatten(1), fb), Hc, Wc) if cat.is_cuda else self.fusion_conv(cat)
 
 
 class ShapePropWeightRegressor(nn.Module):
@@ -543,6 +551,10 @@ class BasicConv2d(nn.Module):
         if (_USE["conv3x3"] and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
                 and w.dtype == x.dtype and ops.conv3x3_ops.supported(x, c.in_channels, c.out_channels, x.shape[2], x.shape[3])):
             return self.bn(ops.conv3x3(x, w))        # conv4 (96 -> 32 at S/8, cod.py:713): NHWC bf16 MFMA kernel
+        if x.is_cuda and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0):
+            # 1x1 conv == GEMM on tokens (cached hipBLASLt plan: a third of the host cost of a MIOpen call); views both ways
+            Bc, _, Hc, Wc = x.shape
+            return self.bn(_tokens_to_nchw(ops.linear(_nchw_to_tokens(x), w.flatten(1), None), Hc, Wc))
         return self.bn(self.conv(x))
 
 

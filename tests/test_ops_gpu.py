@@ -326,7 +326,7 @@ def test_conv3x3_stack_matches_separate_convs(dgtd, shared):
 
 
 @pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 32, 16, 16, 32, 32), (2, 32, 16, 16, 64, 64), (1, 64, 24, 20, 48, 40), (2, 32, 128, 128, 64, 64),
-                                             (2, 8, 7, 9, 19, 13), (1, 96, 32, 32, 64, 64)])
+                                             (2, 8, 7, 9, 19, 13), (1, 96, 32, 32, 64, 64), (2, 24, 2, 2, 16, 16), (1, 24, 16, 16, 128, 128), (2, 8, 3, 5, 40, 33)])
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bilinear_resize_nhwc(dgtd, B, C, Hi, Wi, Ho, Wo, align, dtype):
