@@ -30,6 +30,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_fast(x)
 
 // MODE 0: y = conv(x) + bias          MODE 1: y = gelu(conv(x) + bias)
 // MODE 2: y = aux * gelu'(conv(x) + bias)   (aux = upstream gradient; recomputes the pre-activation)
+// MODE 3: y = conv(x) + bias + aux          (backward w.r.t. x of a residual block: aux = gradient of the skip branch)
 template <typename T, int V> struct VecN { typedef T type __attribute__((ext_vector_type(V))); };
 
 template <typename T, int V, int K, int TX, int MODE>
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
           VT g = *reinterpret_cast<const VT*>(aux + (((size_t)b * H + yy0) * W + xx) * C + c0);
 #pragma unroll
           for (int j = 0; j < V; ++j) o[j] = (T)((float)g[j] * gelu_grad_f(acc[t][j]));
+        } else if (MODE == 3) {
+          VT g = *reinterpret_cast<const VT*>(aux + (((size_t)b * H + yy0) * W + xx) * C + c0);
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = (T)(acc[t][j] + (float)g[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < V; ++j) o[j] = (T)(MODE == 1 ? gelu_f(acc[t][j]) : acc[t][j]);
@@ -274,7 +279,7 @@ int fwd_launch(const void* x, const float* wt, const float* bias, const void* au
   const int64_t total = (int64_t)B * H * cdiv(W, TX) * (C / V);
   const int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
 #define DW_LAUNCH(MODE) hipLaunchKernelGGL((dwconv_fwd_kernel<T, V, K, TX, MODE>), dim3(grid), dim3(256), 0, s, (const T*)x, wt, bias, (const T*)aux, (T*)y, B, H, W, C)
-  if (mode == 0) DW_LAUNCH(0); else if (mode == 1) DW_LAUNCH(1); else DW_LAUNCH(2);
+  if (mode == 0) DW_LAUNCH(0); else if (mode == 1) DW_LAUNCH(1); else if (mode == 2) DW_LAUNCH(2); else DW_LAUNCH(3);
 #undef DW_LAUNCH
   DGTD_CHECK_LAUNCH("dwconv_fwd");
   return 0;
@@ -311,7 +316,7 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
                                int C, int K, int mode, dgtd_dtype dt, dgtd_stream s) {
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_fwd: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
-  DGTD_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || aux), "dwconv_fwd: bad mode %d", mode);
+  DGTD_REQUIRE(mode >= 0 && mode <= 3 && (mode < 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
   DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_fwd: bad dtype %d", (int)dt);
   // measured (profiles/r01_ops_device_times.txt): the LDS-tiled kernel wins 1.6-1.8x for 7x7 (49-tap halo reuse); for 3x3 the direct

@@ -48,7 +48,7 @@ __device__ __forceinline__ void stage_tile(T* __restrict__ tile, const T* __rest
   }
 }
 
-// MODE 0: y = conv + bias   MODE 1: y = gelu(conv + bias)   MODE 2: y = aux * gelu'(conv + bias)
+// MODE 0: y = conv + bias   MODE 1: y = gelu(conv + bias)   MODE 2: y = aux * gelu'(conv + bias)   MODE 3: y = conv + bias + aux
 template <typename T, int K, int MODE>
 __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wt,
                                                                const float* __restrict__ bias, const T* __restrict__ aux,
@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void dwconv_tiled_fwd_kernel(const T* __restri
           r[0] = (T)((float)g[0] * gelu_grad_t(acc[i][0])); r[1] = (T)((float)g[1] * gelu_grad_t(acc[i][1]));
         } else if (MODE == 1) {
           r[0] = (T)gelu_t(acc[i][0]); r[1] = (T)gelu_t(acc[i][1]);
+        } else if (MODE == 3) {
+          PT g = *reinterpret_cast<const PT*>(aux + o);
+          r[0] = (T)(acc[i][0] + (float)g[0]); r[1] = (T)(acc[i][1] + (float)g[1]);
         } else {
           r[0] = (T)acc[i][0]; r[1] = (T)acc[i][1];
         }
@@ -240,7 +243,7 @@ static int tiled_fwd(const void* x, const float* wt, const float* bias, const vo
   DGTD_REQUIRE(tiles < (1LL << 31), "dwconv_tiled_fwd: too many tiles");
   const size_t lds = fwd_lds<T, K>();
 #define TILED(MODE) hipLaunchKernelGGL((dwconv_tiled_fwd_kernel<T, K, MODE>), dim3((unsigned)tiles), dim3(256), lds, s, (const T*)x, wt, bias, (const T*)aux, (T*)y, B, H, W, C)
-  if (mode == 0) TILED(0); else if (mode == 1) TILED(1); else TILED(2);
+  if (mode == 0) TILED(0); else if (mode == 1) TILED(1); else if (mode == 2) TILED(2); else TILED(3);
 #undef TILED
   DGTD_CHECK_LAUNCH("dwconv_tiled_fwd");
   return 0;

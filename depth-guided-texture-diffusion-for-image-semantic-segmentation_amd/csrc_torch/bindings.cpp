@@ -180,6 +180,53 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
   }
 };
 
+// Residual fork: returns (dwconv(x), x); x is used for the skip connection, both gradients arrive here and the skip gradient is
+// added inside the input-gradient convolution (dgtd_dwconv_fwd mode 3) instead of a separate elementwise add per block.
+struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x_, const Tensor& weight_, const c10::optional<Tensor>& bias_) {
+    Tensor x = x_.contiguous(), weight = weight_.contiguous();
+    on_device(x); on_device(weight);
+    const int64_t C = weight.size(0), K = weight.size(3), KK = K * K;
+    const bool has_bias = bias_.has_value() && bias_->defined();
+    TORCH_CHECK(x.size(3) == C && weight.size(1) == 1, "dwconv_nhwc: bad shapes");
+    Tensor bias = has_bias ? bias_->contiguous() : Tensor();
+    Tensor packed = at::empty({(2 * KK + 1) * C}, x.options().dtype(at::kFloat));
+    check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight),
+                           stream()), "dgtd_dwconv_pack");
+    const float* base = packed.data_ptr<float>();
+    Tensor y = DwConvFn::launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, 0, (int)K);
+    ctx->save_for_backward({x, packed});
+    ctx->saved_data["K"] = K;
+    ctx->saved_data["has_bias"] = has_bias;
+    ctx->saved_data["bf16_w"] = weight.scalar_type() == at::kBFloat16;
+    return {y, x_};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &packed = saved[1];
+    const bool has_bias = ctx->saved_data["has_bias"].toBool();
+    const int64_t K = ctx->saved_data["K"].toInt(), KK = K * K, C = x.size(3);
+    const auto wdtype = ctx->saved_data["bf16_w"].toBool() ? at::kBFloat16 : at::kFloat;
+    Tensor skip;
+    if (g[1].defined()) skip = (g[1].scalar_type() == x.scalar_type() ? g[1] : g[1].to(x.scalar_type())).contiguous();
+    if (!g[0].defined()) return {skip, undefined(), undefined()};
+    Tensor du = g[0].contiguous();
+    if (du.scalar_type() != x.scalar_type()) du = du.to(x.scalar_type());
+    const float* base = packed.data_ptr<float>();
+    Tensor dx = skip.defined() ? DwConvFn::launch(du, base + KK * C, nullptr, &skip, 3, (int)K) : DwConvFn::launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);
+    Tensor grads = at::empty({(KK + 1) * C}, x.options().dtype(at::kFloat));
+    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K)}, x.options().dtype(at::kByte));
+    float* gb = grads.data_ptr<float>();
+    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1),
+                                 (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");
+    Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
+    Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
+    check(dgtd_dwconv_unpack_grads(gb, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int)C, (int)K, code(dw), stream()),
+          "dgtd_dwconv_unpack_grads");
+    return {dx, dw, db};
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ x + s[b]*gamma[c]*y
 struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& y_, const c10::optional<Tensor>& s_, const c10::optional<Tensor>& gamma_) {
@@ -567,6 +614,10 @@ std::tuple<Tensor, Tensor> layer_norm_fork(const Tensor& x, const Tensor& w, con
 }
 Tensor sra_attention(const Tensor& q, const Tensor& kv, int64_t heads, double scale) { return SraAttnFn::apply(q, kv, heads, scale); }
 Tensor dwconv_nhwc(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool gelu) { return DwConvFn::apply(x, w, b, gelu); }
+std::tuple<Tensor, Tensor> dwconv_fork(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b) {
+  auto r = DwConvForkFn::apply(x, w, b);
+  return {r[0], r[1]};
+}
 Tensor scale_residual(const Tensor& x, const Tensor& y, const c10::optional<Tensor>& s, const c10::optional<Tensor>& gamma) {
   return ScaleResidualFn::apply(x, y, s, gamma);
 }
@@ -589,6 +640,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("layer_norm_fork(Tensor(a) x, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor(a))", &layer_norm_fork);
   m.def("sra_attention(Tensor q, Tensor kv, int heads, float scale) -> Tensor", &sra_attention);
   m.def("dwconv_nhwc(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> Tensor", &dwconv_nhwc);
+  m.def("dwconv_fork(Tensor(a) x, Tensor weight, Tensor? bias) -> (Tensor, Tensor(a))", &dwconv_fork);
   m.def("scale_residual(Tensor x, Tensor y, Tensor? s, Tensor? gamma) -> Tensor", &scale_residual);
   m.def("linear(Tensor x, Tensor weight, Tensor? bias, int dtype_code) -> Tensor", &linear);
   m.def("linear_gelu(Tensor x, Tensor weight, Tensor bias, int dtype_code) -> Tensor", &linear_gelu);

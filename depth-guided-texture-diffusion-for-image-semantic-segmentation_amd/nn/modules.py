@@ -259,11 +259,12 @@ class convnext_Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward_nhwc(self, x):
-        y = ops.dwconv_nhwc(x, *wb(self.dwconv))
         s = self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
         if _USE["fused_linear"] and x.is_cuda:   # pwconv1+GELU and pwconv2+gamma+DropPath+residual as two nodes with fused backward passes
+            y, xs = ops.dwconv_fork(x, *wb(self.dwconv)) if _USE["ln_fork"] else (ops.dwconv_nhwc(x, *wb(self.dwconv)), x)
             h = ops.linear_gelu(self.norm(y), *wb(self.pwconv1))
-            return ops.linear_residual(h, *wb(self.pwconv2), x, s, self.gamma)
+            return ops.linear_residual(h, *wb(self.pwconv2), xs, s, self.gamma)
+        y = ops.dwconv_nhwc(x, *wb(self.dwconv))
         y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
         return ops.scale_residual(x, y, s, self.gamma)   # x + DropPath(gamma * y) in one pass
 

@@ -66,3 +66,13 @@ def dwconv_nhwc(x: torch.Tensor, weight: torch.Tensor, bias, gelu: bool = False)
     if nat is not None and x.is_cuda:
         return nat.dwconv_nhwc(x, weight, bias, bool(gelu))
     return _DwConvFn.apply(x.contiguous(), weight.contiguous(), bias, gelu)
+
+
+def dwconv_fork(x, weight, bias=None):
+    """(dwconv(x), x) for a residual block whose skip connection starts at the convolution's input (convnext_Block, cod.py:1104-1116):
+    use the second value for the skip; with the C++ bindings the skip gradient is added inside the input-gradient convolution
+    (dgtd_dwconv_fwd mode 3) instead of a separate elementwise add."""
+    nat = _native.ops()
+    if nat is not None and x.is_cuda:
+        return nat.dwconv_fork(x, weight, bias)
+    return dwconv_nhwc(x, weight, bias), x

@@ -71,6 +71,7 @@ int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void
  * transposed so that tap rows are contiguous in C); bias fp32 [C] or NULL.  K in {3, 7}.
  * mode 0: y = conv(x)+bias   mode 1: y = gelu(conv(x)+bias)   mode 2: y = aux * gelu'(conv(x)+bias)
  * (mode 2 is the backward through the fused GELU: aux = upstream gradient, pre-activation recomputed).
+ * mode 3: y = conv(x)+bias+aux (the input gradient of a residual block: aux = gradient arriving through the skip connection).
  * Backward w.r.t. x = mode 0 applied to the gradient with the spatially flipped filter.            */
 int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y,
                     int B, int H, int W, int C, int K, int mode, dgtd_dtype dt, dgtd_stream s);

@@ -425,3 +425,24 @@ def test_layernorm_fork_adds_skip_gradient(dgtd, C, dtype):
     h2, = torch.autograd.grad(y2, xs, g1)
     g2x, = torch.autograd.grad(F.layer_norm(xr, (C,), w, b, 1e-6), xr, g1.float())
     torch.testing.assert_close(h2.float(), g2x, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("K,C,H", [(7, 128, 16), (7, 512, 12), (3, 256, 10)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv_fork_adds_skip_gradient(dgtd, K, C, H, dtype):
+    """(dwconv(x), x): the skip-branch gradient is added inside the input-gradient convolution (mode 3)."""
+    x = _rand(2, H, H, C, seed=1, dtype=dtype)
+    w = (_rand(C, 1, K, K, seed=2) / K).to(dtype).requires_grad_()
+    b = (0.1 * _rand(C, seed=3)).to(dtype).requires_grad_()
+    g1, g2 = _rand(2, H, H, C, seed=4, dtype=dtype), _rand(2, H, H, C, seed=5, dtype=dtype)
+    xr, wr, br = x.float().requires_grad_(), w.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=K // 2, groups=C).permute(0, 2, 3, 1)
+    gx, gw, gb = torch.autograd.grad([ref, xr * 1.0], (xr, wr, br), [g1.float(), g2.float()])
+    xs = x.clone().requires_grad_()
+    y, skip = dgtd.ops.dwconv_fork(xs, w, b)
+    hx, hw, hb = torch.autograd.grad([y, skip * 1.0], (xs, w, b), [g1, g2])
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
+    torch.testing.assert_close(hw.float(), gw, atol=tol * 8, rtol=5e-2)
+    torch.testing.assert_close(hb.float(), gb, atol=tol * 8, rtol=5e-2)
