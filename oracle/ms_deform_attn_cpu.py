@@ -1,29 +1,40 @@
 """TEST INFRASTRUCTURE — CPU restatement of the reference's multi-scale deformable attention
-(twig/ops/functions/ms_deform_attn_func.py:49-71, ``ms_deform_attn_core_pytorch``: per level, F.grid_sample of the value map at
-2*loc-1 with bilinear / zeros / align_corners=False, weighted by the attention weights and summed over levels and points).
+(semantics of twig/ops/functions/ms_deform_attn_func.py:49-71, ``ms_deform_attn_core_pytorch``, and of the kernels behind
+MSDA.ms_deform_attn_forward: bilinear sampling of each level's value map at the sampling locations, zero padding,
+align_corners=False, weighted by the attention weights and summed over levels and points).
 Pinned against the reference's own function (imported in the build container by oracle/make_golden.py through a stub for the
 compiled ``MultiScaleDeformableAttention`` module) with the vectors in tests/golden/msda.npz, and by the reference's acceptance
 thresholds (twig/ops/test.py:43 allclose in double, :68 rtol 1e-2 / atol 1e-3 in float, :96-99 gradcheck)."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 
 def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights):
+    """First-principles evaluation (explicit corner gathers) of what the reference computes with one F.grid_sample per level:
+    pixel coordinates h = y*H - 0.5, w = x*W - 0.5 (align_corners=False), bilinear weights on the four neighbours, neighbours
+    outside the map contribute zero (padding_mode='zeros').  Differentiable through torch ops, so autograd gives the oracle
+    gradients w.r.t. value, locations and weights."""
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_locations.shape
-    sizes = [int(h) * int(w) for h, w in spatial_shapes]
-    levels = value.split(sizes, dim=1)
-    grids = 2 * sampling_locations - 1
-    sampled = []
-    for lid, (h, w) in enumerate(spatial_shapes):
-        v = levels[lid].flatten(2).transpose(1, 2).reshape(N * M, D, int(h), int(w))           # [N*M, D, H, W]
-        g = grids[:, :, :, lid].transpose(1, 2).flatten(0, 1)                                    # [N*M, Lq, P, 2]
-        sampled.append(F.grid_sample(v, g, mode="bilinear", padding_mode="zeros", align_corners=False))   # [N*M, D, Lq, P]
-    a = attention_weights.transpose(1, 2).reshape(N * M, 1, Lq, L * P)
-    out = (torch.stack(sampled, dim=-2).flatten(-2) * a).sum(-1).view(N, M * D, Lq)
-    return out.transpose(1, 2).contiguous()
+    out = value.new_zeros(N, Lq, M, D)
+    start = 0
+    for lvl, (H, W) in enumerate((int(h), int(w)) for h, w in spatial_shapes):
+        maps = value[:, start:start + H * W].permute(0, 2, 1, 3)            # [N, M, H*W, D]
+        start += H * W
+        px = sampling_locations[:, :, :, lvl, :, 0] * W - 0.5                # [N, Lq, M, P]
+        py = sampling_locations[:, :, :, lvl, :, 1] * H - 0.5
+        x0, y0 = torch.floor(px), torch.floor(py)
+        fx, fy = px - x0, py - y0
+        a = attention_weights[:, :, :, lvl, :]                               # [N, Lq, M, P]
+        for dy, dx, wgt in ((0, 0, (1 - fy) * (1 - fx)), (0, 1, (1 - fy) * fx), (1, 0, fy * (1 - fx)), (1, 1, fy * fx)):
+            xi, yi = x0 + dx, y0 + dy
+            inside = ((xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)).to(value.dtype)
+            flat = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long()      # [N, Lq, M, P]
+            idx = flat.permute(0, 2, 1, 3).reshape(N, M, Lq * P, 1).expand(N, M, Lq * P, D)
+            corner = torch.gather(maps, 2, idx).reshape(N, M, Lq, P, D).permute(0, 2, 1, 3, 4)    # [N, Lq, M, P, D]
+            out = out + ((a * wgt * inside).unsqueeze(-1) * corner).sum(3)
+    return out.reshape(N, Lq, M * D)
 
 
 def case_inputs(name: str, N, M, D, Lq, shapes, P, dtype=torch.float64):

@@ -28,11 +28,11 @@ def _run_oracle(name, dtype=torch.float64):
 @pytest.mark.parametrize("name", list(mc.CASES))
 def test_oracle_matches_reference_vectors(G, name):
     _, y, gv, gl, ga = _run_oracle(name)
-    np.testing.assert_allclose(y.numpy(), G[f"{name}.out"], rtol=1e-12, atol=1e-15)
-    np.testing.assert_allclose(gl.numpy(), G[f"{name}.grad_loc"], rtol=1e-10, atol=1e-14)
-    np.testing.assert_allclose(ga.numpy(), G[f"{name}.grad_attn"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(y.numpy(), G[f"{name}.out"], rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(gl.numpy(), G[f"{name}.grad_loc"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(ga.numpy(), G[f"{name}.grad_attn"], rtol=1e-9, atol=1e-14)
     if f"{name}.grad_value" in G:
-        np.testing.assert_allclose(gv.numpy(), G[f"{name}.grad_value"], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(gv.numpy(), G[f"{name}.grad_value"], rtol=1e-9, atol=1e-14)
     else:
         f = gv.double().flatten()
         np.testing.assert_allclose(f[::int(G[f"{name}.grad_value.step"])].float().numpy(), G[f"{name}.grad_value.samples"], rtol=1e-6, atol=1e-9)
