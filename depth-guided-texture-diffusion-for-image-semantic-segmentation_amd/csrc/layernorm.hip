@@ -59,43 +59,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       bt[i][j] = (c < cpr) ? beta[c * V + j] : 0.f;
     }
   }
-  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < rows; r0 += (int64_t)gridDim.x * rows_per_block) {
-    int64_t row = r0 + wave * rpw + gi;
-    bool ok = row < rows;
-    float v[NPL][V];
-    if (ok) load_row<T, NPL>(x + row * C, cpr, gl, G, v);
-    else {
+  constexpr int U = (NPL <= 2) ? 4 : 2;   // rows in flight per lane group: all row loads are issued before the first reduction
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block * U; r0 < rows; r0 += (int64_t)gridDim.x * rows_per_block * U) {
+    float v[U][NPL][V];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + (int64_t)u * rows_per_block + wave * rpw + gi;
+      ok[u] = row < rows;
+      if (ok[u]) load_row<T, NPL>(x + row * C, cpr, gl, G, v[u]);
+      else {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[u][i][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + (int64_t)u * rows_per_block + wave * rpw + gi;
+      float s = 0.f;
 #pragma unroll
       for (int i = 0; i < NPL; ++i)
 #pragma unroll
-        for (int j = 0; j < V; ++j) v[i][j] = 0.f;
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-#pragma unroll
-      for (int j = 0; j < V; ++j) s += v[i][j];
-    const float mu = group_sum(s, G) * invC;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      bool in = (gl + i * G) < cpr;
-#pragma unroll
-      for (int j = 0; j < V; ++j) { float d = in ? v[i][j] - mu : 0.f; q += d * d; }
-    }
-    const float rs = rsqrtf(group_sum(q, G) * invC + eps);
-    if (ok) {
+        for (int j = 0; j < V; ++j) s += v[u][i][j];
+      const float mu = group_sum(s, G) * invC;
+      float q = 0.f;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        int c = gl + i * G;
-        if (c < cpr) {
-          VT o;
+        bool in = (gl + i * G) < cpr;
 #pragma unroll
-          for (int j = 0; j < V; ++j) o[j] = (T)((v[i][j] - mu) * rs * gm[i][j] + bt[i][j]);
-          *reinterpret_cast<VT*>(y + row * C + (size_t)c * V) = o;
-        }
+        for (int j = 0; j < V; ++j) { float d = in ? v[u][i][j] - mu : 0.f; q += d * d; }
       }
-      if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+      const float rs = rsqrtf(group_sum(q, G) * invC + eps);
+      if (ok[u]) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          int c = gl + i * G;
+          if (c < cpr) {
+            VT o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = (T)((v[u][i][j] - mu) * rs * gm[i][j] + bt[i][j]);
+            *reinterpret_cast<VT*>(y + row * C + (size_t)c * V) = o;
+          }
+        }
+        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+      }
     }
   }
 }
@@ -248,7 +257,8 @@ int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y,
   LnGeom g = ln_geom<T>(C);
   DGTD_REQUIRE(g.npl <= LN_MAX_NPL, "layernorm: C=%d too large", C);
   if (rows == 0) return 0;
-  int grid = (int)std::min<int64_t>(cdiv(rows, g.rows_per_block), 256 * 8);
+  const int U = g.npl <= 2 ? 4 : 2;     // must match ln_fwd_kernel
+  int grid = (int)std::min<int64_t>(cdiv(rows, g.rows_per_block * U), 256 * 8);
 #define LN_FWD(NPL) hipLaunchKernelGGL((ln_fwd_kernel<T, NPL>), dim3(grid), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, g.G)
   switch (g.npl) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break; default: LN_FWD(4); }
 #undef LN_FWD

@@ -13,7 +13,7 @@ os.environ.setdefault("DGTD_TORCH_BINDINGS", "0")
 import dgtd  # noqa: E402
 
 dev, bf = "cuda", torch.bfloat16
-REPS = 3
+REPS = int(os.environ.get("REPS", 3))
 
 
 def dw(K, H, C, gelu):
