@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgtd.so")
 
-F32, BF16, F64 = 0, 1, 2
+F32, BF16, F64, F16 = 0, 1, 2, 3
 _vp, _fp, _i, _i64, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); kept in lock-step with include/dgtd.h (tests/test_abi.py parses the header)
@@ -48,6 +48,9 @@ SIGNATURES = {
     "dgtd_diffuse_tail_bwd_workspace": (_i64, [_i]),
     "dgtd_diffuse_tail_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _vp]),
+    "dgtd_found_inf": (_i, [_fp, _i64, _fp, _vp]),
+    "dgtd_loss_scale_update": (_i, [_fp, _f, _f, _i, _vp]),
     "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ms_deform_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_preprocess_workspace": (_i64, [_i, _i, _i, _i]),
@@ -58,10 +61,10 @@ SIGNATURES = {
     "dgtd_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_supported": (_i, [_i, _i, _i, _i]),
-    "dgtd_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_flip": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dgtd_conv3x3_wgrad_workspace": (_i64, [_i, _i, _i, _i, _i, _i]),
-    "dgtd_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ca_gate_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -92,7 +95,9 @@ def dtype_code(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise DgtdError(f"dgtd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return F16
+    raise DgtdError(f"dgtd kernels take float32, bfloat16 or float16 tensors, got {t.dtype}")
 
 
 def stream_ptr() -> int:

@@ -56,23 +56,27 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 //           operands (Z = X^T B).
 //   dQ    : the forward kernel's shape: K and V staged once in LDS (row-major), lane = query, S^T/dP^T with rows = key, dS^T
 //           fed back as the B operand and K^T fragments taken with ds_read_b64_tr_b16 (Y = A X).  lse and delta are lane-local.
+template <typename T>
 struct DkdvSmem {
   static constexpr int QS = 72;
-  bf16_t q[2][32][QS];
-  bf16_t g[2][32][QS];
+  T q[2][32][QS];
+  T g[2][32][QS];
   float lse2[2][32];
   float dl[2][32];
 };
 
 constexpr int KGROUP = 128;   // keys per dK/dV workgroup (4 waves x 32)
 
-__global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+template <typename T>
+__global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const T* __restrict__ q, const T* __restrict__ kv,
+                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dkv,
                                                             int N, int Nkv, int heads, int kgroups, float scale, int qch,
                                                             int use_atomics) {
-  __shared__ __attribute__((aligned(16))) DkdvSmem sm;
-  constexpr int QS = DkdvSmem::QS;
+  typedef T bf16_t;                                  // T = bf16_t or f16_t
+  typedef typename Vec16<T>::type bf16x8;
+  __shared__ __attribute__((aligned(16))) DkdvSmem<T> sm;
+  constexpr int QS = DkdvSmem<T>::QS;
   const int C = heads * 64;
   const int b = blockIdx.z, hd = blockIdx.y / kgroups, kg = blockIdx.y % kgroups;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -143,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
       for (int s = 0; s < 4; ++s) {
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&sm.q[cur][r][16 * s + 8 * h]);
         const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&sm.g[cur][r][16 * s + 8 * h]);
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sA, 0, 0, 0);   // S[q][key]
-        pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[s], pA, 0, 0, 0);   // dP[q][key]
+        sA = mfma16(qf, kf[s], sA);   // S[q][key]
+        pA = mfma16(gf, vf[s], pA);   // dP[q][key]
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
           // column fragments: lane (d = nb*32 + r, half h), element j <-> query 16*s2 + 8*(j>>2) + 4h + (j&3)
           const bf16x8 gb = lds_tr_frag(&sm.g[cur][0][0], QS, 16 * s2, nb * 32, lane);
           const bf16x8 qb = lds_tr_frag(&sm.q[cur][0][0], QS, 16 * s2, nb * 32, lane);
-          dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gb, dv[nb], 0, 0, 0);  // dV[key][d]
-          dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb, dk[nb], 0, 0, 0);  // dK[key][d]
+          dv[nb] = mfma16(pf, gb, dv[nb]);  // dV[key][d]
+          dk[nb] = mfma16(df, qb, dk[nb]);  // dK[key][d]
         }
       }
     }
@@ -187,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const bf16_t* __rest
   }
 }
 
-template <int KCH>
-__global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16_t* __restrict__ dq,
+template <typename T, int KCH>
+__global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const T* __restrict__ q, const T* __restrict__ kv,
+                                                          const T* __restrict__ dout, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, T* __restrict__ dq,
                                                           int N, int Nkv, int heads, float scale, int qtw) {
+  typedef T bf16_t;
+  typedef typename Vec16<T>::type bf16x8;
+  typedef typename Vec8<T>::type bf16x4;
   constexpr int KS = 72, NT = KCH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -253,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const bf16_t* __restri
         for (int s = 0; s < 4; ++s) {
           const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * KS + 16 * s + 8 * h);
           const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * KS + 16 * s + 8 * h);
-          sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], sT, 0, 0, 0);   // S^T[key][q]
-          pT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, gf[s], pT, 0, 0, 0);   // dP^T[key][q]
+          sT = mfma16(ka, qf[s], sT);   // S^T[key][q]
+          pT = mfma16(va, gf[s], pT);   // dP^T[key][q]
         }
         const bool ragged = (kn & 31) && (kt == ntiles - 1);
 #pragma unroll
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const bf16_t* __restri
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const bf16x8 ka = lds_tr_frag(Ks, KS, kt * 32 + 16 * s2, nb * 32, lane);      // K^T fragment
-            dqa[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, df, dqa[nb], 0, 0, 0);  // dQ^T[d][q]
+            dqa[nb] = mfma16(ka, df, dqa[nb]);  // dQ^T[d][q]
           }
         }
       }
@@ -483,13 +490,13 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
                                  void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
                                  dgtd_dtype dt, dgtd_stream s) {
   DGTD_REQUIRE(B > 0 && N > 0 && Nkv > 0 && heads > 0, "sra_attn_bwd: bad sizes B=%d N=%d Nkv=%d heads=%d", B, N, Nkv, heads);
-  DGTD_REQUIRE(dt == DGTD_F32 || dt == DGTD_BF16, "sra_attn_bwd: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(dt == DGTD_F32 || DGTD_IS_HALF(dt), "sra_attn_bwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   float* delta = (float*)workspace;
   const int64_t items = (int64_t)B * N * heads;
   const int qtiles = (int)cdiv(N, 32);
-  if (dt == DGTD_BF16) {
-    hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, heads);
+  if (DGTD_IS_HALF(dt)) {
+    DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((attn_delta_kernel<T_>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const T_*)out, (const T_*)dout, delta, B, N, heads));
     DGTD_CHECK_LAUNCH("attn_delta");
     // dK/dV: workgroup = 128 keys (4 waves) x a chunk of query tiles.  Keys are split across workgroups; queries are split
     // only as far as needed to put ~1 workgroup on every CU, because every extra query chunk costs one more fp32-atomic flush
@@ -499,8 +506,8 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
     const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(256, (int64_t)B * heads * kgroups)));
     const int qch = (int)cdiv(qtiles, nq);
     const int nqc = (int)cdiv(qtiles, qch);
-    hipLaunchKernelGGL(sra_bwd_dkdv_bf16, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv,
-                       (const bf16_t*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, kgroups, scale, qch, nqc > 1 ? 1 : 0);
+    DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL(sra_bwd_dkdv_bf16<T_>, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const T_*)q, (const T_*)kv,
+                       (const T_*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, kgroups, scale, qch, nqc > 1 ? 1 : 0));
     DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv");
     // dQ: forward-shaped launch
     int qtw = 1;
@@ -508,12 +515,12 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
     dim3 grid((unsigned)cdiv(N, 128 * qtw), heads, B);
     if (Nkv <= 64) {
       constexpr int KCH = 64;
-      hipLaunchKernelGGL((sra_bwd_dq_bf16<KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const bf16_t*)q, (const bf16_t*)kv,
-                         (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dq, N, Nkv, heads, scale, qtw);
+      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
+                         (const T_*)dout, lse, (const float*)delta, (T_*)dq, N, Nkv, heads, scale, qtw));
     } else {
       constexpr int KCH = 256;
-      hipLaunchKernelGGL((sra_bwd_dq_bf16<KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const bf16_t*)q, (const bf16_t*)kv,
-                         (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dq, N, Nkv, heads, scale, qtw);
+      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
+                         (const T_*)dout, lse, (const float*)delta, (T_*)dq, N, Nkv, heads, scale, qtw));
     }
   } else {
     hipLaunchKernelGGL((attn_delta_kernel<float>), dim3((unsigned)cdiv(items * 16, 256)), dim3(256), 0, st, (const float*)out, (const float*)dout, delta, B, N, heads);

@@ -24,10 +24,13 @@ constexpr float LN2 = 0.6931471805599453f;
 // product come from the transposing LDS read (ds_read_b64_tr_b16), so nothing is transposed at staging time.
 // KCH keys are staged per LDS chunk; the score tile is processed KREG keys at a time (online softmax between units) so the
 // kernel stays at <= 256 registers -> 2 waves per SIMD: one wave's softmax VALU overlaps the other's MFMA.
-template <int KCH, int KREG>
-__global__ __launch_bounds__(256, 2) void sra_fwd_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                    bf16_t* __restrict__ out, float* __restrict__ lse,
+template <typename T, int KCH, int KREG>
+__global__ __launch_bounds__(256, 2) void sra_fwd_bf16(const T* __restrict__ q, const T* __restrict__ kv,
+                                                    T* __restrict__ out, float* __restrict__ lse,
                                                     int N, int Nkv, int heads, float scale_log2e, int qtw) {
+  typedef T bf16_t;                                  // T = bf16_t or f16_t: same kernel on v_mfma_f32_32x32x16_bf16 / _f16
+  typedef typename Vec16<T>::type bf16x8;
+  typedef typename Vec8<T>::type bf16x4;
   constexpr int KS = 72, NT = KREG / 32, NU = KCH / KREG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void sra_fwd_bf16(const bf16_t* __restrict_
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (ubase + kt * 32 + r) * KS + 16 * s + 8 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], acc, 0, 0, 0);
+            acc = mfma16(a, qf[s], acc);
           }
           if ((kn & 31) && ubase + kt * 32 + 32 > kn) {   // ragged last tile only: padded keys leave the softmax
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void sra_fwd_bf16(const bf16_t* __restrict_
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
               const bf16x8 a = lds_tr_frag(Vs, KS, ubase + kt * 32 + 16 * s2, nb * 32, lane);
-              o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[nb], 0, 0, 0);
+              o[nb] = mfma16(a, pb, o[nb]);
             }
           }
         }
@@ -316,15 +319,15 @@ extern "C" int dgtd_sra_attn_fwd(const void* q, const void* kv, void* out, float
   const int qtw = pick_qtw(N, B * heads);
   dim3 grid((unsigned)cdiv(N, 128 * qtw), heads, B), block(256);
   const float sl2 = scale * LOG2E;
-  if (dt == DGTD_BF16) {
+  if (DGTD_IS_HALF(dt)) {
     if (Nkv <= 64) {
       constexpr int KCH = 64;
       size_t lds = (size_t)(2 * KCH * 72) * 2;
-      hipLaunchKernelGGL((sra_fwd_bf16<KCH, 64>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
+      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_fwd_bf16<T_, KCH, 64>), grid, block, lds, (hipStream_t)s, (const T_*)q, (const T_*)kv, (T_*)out, lse, N, Nkv, heads, sl2, qtw));
     } else {
       constexpr int KCH = 256;
       size_t lds = (size_t)(2 * KCH * 72) * 2;
-      hipLaunchKernelGGL((sra_fwd_bf16<KCH, 128>), grid, block, lds, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, N, Nkv, heads, sl2, qtw);
+      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_fwd_bf16<T_, KCH, 128>), grid, block, lds, (hipStream_t)s, (const T_*)q, (const T_*)kv, (T_*)out, lse, N, Nkv, heads, sl2, qtw));
     }
   } else if (dt == DGTD_F32) {
     if (Nkv <= 64) {

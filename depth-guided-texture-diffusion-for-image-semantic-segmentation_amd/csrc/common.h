@@ -8,6 +8,9 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -26,6 +29,23 @@ template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { static constexpr int N = 4; typedef f32x4 type; };
 template <> struct Vec16<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+template <> struct Vec16<f16_t> { static constexpr int N = 8; typedef f16x8 type; };
+// 8-byte vector of a 2-byte type
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec8<f16_t> { typedef f16x4 type; };
+
+// the 16-bit MFMA of the I/O type: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same shape, same cycles)
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// the two 16-bit I/O types (DGTD_BF16 / DGTD_F16)
+#define DGTD_IS_HALF(dt) ((dt) == DGTD_BF16 || (dt) == DGTD_F16)
+// run STMT with T_ bound to the element type of dtype code `dt` (float unless one of the 16-bit codes)
+#define DGTD_DISPATCH(dt, STMT) do { if ((dt) == DGTD_BF16) { typedef bf16_t T_; STMT; } else if ((dt) == DGTD_F16) { typedef f16_t T_; STMT; } \
+                                     else { typedef float T_; STMT; } } while (0)
+// same for the 16-bit types only (callers have checked DGTD_IS_HALF)
+#define DGTD_DISPATCH_HALF(dt, STMT) do { if ((dt) == DGTD_F16) { typedef f16_t T_; STMT; } else { typedef bf16_t T_; STMT; } } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -53,14 +73,16 @@ __device__ __forceinline__ constexpr int mfma_row(int reg, int h) { return (reg 
 // a 4-row x 16-column block: lane 4q+p supplies the address of row q, columns 4p..4p+3 and receives column (lane&15).
 // Requirements: EXEC all ones, 8-byte aligned addresses (stride*2 and col0*2 multiples of 8).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_tr_frag(const bf16_t* base, int stride, int row0, int col0, int lane) {
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type lds_tr_frag(const T* base, int stride, int row0, int col0, int lane) {
   const int i = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
-  const bf16_t* p = base + (row0 + 4 * h + (i >> 2)) * stride + col0 + 16 * g1 + 4 * (i & 3);
+  const T* p = base + (row0 + 4 * h + (i >> 2)) * stride + col0 + 16 * g1 + 4 * (i & 3);
   typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  typedef typename Vec8<T>::type V4;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * stride));
-  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-  bf16x8 f;
+  V4 l4 = __builtin_bit_cast(V4, lo), h4 = __builtin_bit_cast(V4, hi);
+  typename Vec16<T>::type f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { f[j] = l4[j]; f[4 + j] = h4[j]; }
   return f;

@@ -17,21 +17,23 @@
 
 namespace {
 
-typedef bf16x8 __attribute__((address_space(3))) * lds_v8;
-
-__device__ __forceinline__ bf16x8 zero8() {
-  bf16x8 v;
+// T = bf16_t or f16_t (same kernels, v_mfma_f32_32x32x16_bf16 / _f16)
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type zero8() {
+  typename Vec16<T>::type v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+  for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
   return v;
 }
 
-__device__ __forceinline__ bf16x8 load_masked(const bf16_t* __restrict__ src, const bf16_t* __restrict__ mask, size_t o) {
-  bf16x8 v = *reinterpret_cast<const bf16x8*>(src + o);
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type load_masked(const T* __restrict__ src, const T* __restrict__ mask, size_t o) {
+  typedef typename Vec16<T>::type V8;
+  V8 v = *reinterpret_cast<const V8*>(src + o);
   if (mask) {
-    const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + o);
+    const V8 m = *reinterpret_cast<const V8*>(mask + o);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : (bf16_t)0.f;
+    for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : (T)0.f;
   }
   return v;
 }
@@ -43,14 +45,17 @@ __device__ __forceinline__ bf16x8 load_masked(const bf16_t* __restrict__ src, co
 // K runs tap by tap; within a tap an MFMA step covers channel groups 2j (lanes 0-31) and 2j+1 (lanes 32-63).
 // A = kernel rows (co): the [Co][CI] slice of each tap is copied to LDS with coalesced loads (fetched one or two taps ahead into
 // registers) - reading the fragments straight from global memory costs one cache line per lane and was the bottleneck.  D[co][pixel].
-template <int CI, int NT, int MT, int TWX>
-__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ mask,
-                                                          const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
-                                                          bf16_t* __restrict__ y, int H, int W, int Co, int relu, int tiles_w,
+template <typename T, int CI, int NT, int MT, int TWX>
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ mask,
+                                                          const T* __restrict__ w, const T* __restrict__ bias,
+                                                          T* __restrict__ y, int H, int W, int Co, int relu, int tiles_w,
                                                           long x_zs, long w_zs, long y_zs) {
   constexpr int G = CI / 8, RW = 32 / TWX, TH = 4 * MT * RW, LW = TWX + 2, LP = (TH + 2) * LW;
   constexpr int COP = NT * 32, GP = G | 1, WSZ = COP * GP, NWR = (COP * G + 255) / 256;
   constexpr int WB = ((size_t)G * LP + 2 * WSZ) * 16 <= 65536 ? 2 : 1;   // double-buffer the kernel slices when LDS allows
+  typedef typename Vec16<T>::type bf16x8;
+  typedef typename Vec8<T>::type bf16x4;
+  typedef T bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* tile = reinterpret_cast<bf16x8*>(smem);   // [G][LP]
   bf16x8* wbuf = tile + G * LP;                      // [WB][COP][GP]
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < NWR; ++i) {
       const int c = tid + i * 256;
       const int co = c / G, g = c % G;
-      wr[i] = (c < COP * G && co < Co) ? *reinterpret_cast<const bf16x8*>(wz + ((size_t)co * 9 + tap) * CI + g * 8) : zero8();
+      wr[i] = (c < COP * G && co < Co) ? *reinterpret_cast<const bf16x8*>(wz + ((size_t)co * 9 + tap) * CI + g * 8) : zero8<T>();
     }
   };
   auto wstore = [&](int buf) {
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
     const int pix = c / G, g = c % G;
     const int pr = pix / LW, pc = pix % LW;
     const int h = h0 - 1 + pr, ww = w0 - 1 + pc;
-    bf16x8 v = zero8();
+    bf16x8 v = zero8<T>();
     if (h >= 0 && h < H && ww >= 0 && ww < W) v = load_masked(xb, mb, ((size_t)h * W + ww) * CI + g * 8);
     tile[g * LP + pix] = v;
   }
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
       const int g = valid ? 2 * js + half : 2 * js;
       bf16x8 wf[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[nt] = valid ? wb[(nt * 32 + l31) * GP + g] : zero8();
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = valid ? wb[(nt * 32 + l31) * GP + g] : zero8<T>();
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const bf16x8 xf = tile[g * LP + basepix[mt] + tapoff];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(wf[nt], xf, acc[mt][nt]);
       }
     }
   }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const bf16_t* __restri
 }
 
 // w [Z][Co][3][3][Ci] -> wt [Z][Ci][3][3][Co], taps flipped: wt[z][ci][ky][kx][co] = w[z][co][2-ky][2-kx][ci]
-__global__ __launch_bounds__(256) void conv3x3_flip_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int Co, int Ci, long n) {
+__global__ __launch_bounds__(256) void conv3x3_flip_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wt, int Co, int Ci, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int co = (int)(i % Co);
@@ -184,13 +189,15 @@ constexpr int lds_stride_for(int c) {   // row stride (elements) of a pixel-majo
 // (9/NS)*ceil(CI/32) (tap, 32-channel block) tiles of its filter rows, distributed round-robin over the 4 waves; loops over its
 // share of TH x TW pixel tiles, K = 16 pixels per MFMA.  NS = 3 when CI > 32 (more workgroups for the same partial-sum volume).
 // partial [Z][MTt][P][32 co][9][CB*32 ci] fp32 (+ bias partial [Z][MTt][P][32], written by the ky-group 0 workgroups).
-template <int CI, int TH, int TW>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                            const bf16_t* __restrict__ mask, float* __restrict__ partial,
+template <typename T, int CI, int TH, int TW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const T* __restrict__ mask, float* __restrict__ partial,
                                                             float* __restrict__ partial_b, int B, int H, int W, int Co,
                                                             int tiles_w, int tiles_h, long x_zs, long dy_zs) {
   constexpr int G = CI / 8, CB = (CI + 31) / 32, XS = lds_stride_for(CI), LW = TW + 2, LP = (TH + 2) * LW, NPIX = TH * TW;
   constexpr int NS = CI > 32 ? 3 : 1, NTN = 9 * CB / NS, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
+  typedef typename Vec16<T>::type bf16x8;
+  typedef T bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* xt = reinterpret_cast<bf16_t*>(smem);          // [LP][XS]
   bf16_t* dt = xt + LP * XS;                             // [NPIX][32]
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
   if (CI % 32) {   // pad columns of the x tile are read by the transposing loads: keep them finite
     for (int c = tid; c < LP * (CB * 32 - CI) / 8; c += 256) {
       const int pix = c / ((CB * 32 - CI) / 8), g = c % ((CB * 32 - CI) / 8);
-      *reinterpret_cast<bf16x8*>(xt + pix * XS + CI + g * 8) = zero8();
+      *reinterpret_cast<bf16x8*>(xt + pix * XS + CI + g * 8) = zero8<T>();
     }
   }
   // The next pixel tile is fetched into registers while the MFMAs of the current one run (one workgroup per CU: nothing else
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
       const int pix = c / G, g = c % G;
       const int pr = pix / LW, pc = pix % LW;
       const int h = h0 - 1 + pr, ww = w0 - 1 + pc;
-      xr[i] = zero8();
+      xr[i] = zero8<T>();
       if (c < LP * G && h >= 0 && h < H && ww >= 0 && ww < W) xr[i] = *reinterpret_cast<const bf16x8*>(xb + ((size_t)h * W + ww) * CI + g * 8);
     }
 #pragma unroll
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
       const int c = tid + i * 256;
       const int pix = c >> 2, q = c & 3;
       const int h = h0 + pix / TW, ww = w0 + pix % TW, co = mt * 32 + q * 8;
-      dr[i] = zero8();
+      dr[i] = zero8<T>();
       if (c < NPIX * 4 && h < H && ww < W && co < Co) dr[i] = load_masked(db, mb, ((size_t)h * W + ww) * Co + co);
     }
   };
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
         if (tl < NTN) {
           const int tap = kg * (9 / NS) + tl / CB, cb = tl % CB;
           const bf16x8 bfr = lds_tr_frag(xt, XS, (r + tap / 3) * LW + c0 + tap % 3, cb * 32, lane);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[i], 0, 0, 0);
+          acc[i] = mfma16(a, bfr, acc[i]);
         }
       }
     }
@@ -296,8 +303,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
 }
 
 // dw [Z][Co][9][CI] bf16 and db [Z][Co] bf16 from the partials (fixed summation order)
+template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
-                                                                   bf16_t* __restrict__ dw, bf16_t* __restrict__ db, int Z, int Co,
+                                                                   T* __restrict__ dw, T* __restrict__ db, int Z, int Co,
                                                                    int CI, int CB, int MTt, int P) {
   const long n = (long)Z * Co * 9 * CI;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
       s1 += (v4 + v5) + (v6 + v7);
     }
     for (; q < P; ++q) s0 += pp[q * ps];
-    dw[i] = (bf16_t)(s0 + s1);
+    dw[i] = (T)(s0 + s1);
   }
   if (db && i < (long)Z * Co) {
     const int co = (int)(i % Co);
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
     const float* pb = partial_b + (((size_t)z * MTt + (co >> 5)) * P) * 32 + (co & 31);
     float s = 0.f;
     for (int q = 0; q < P; ++q) s += pb[(size_t)q * 32];
-    db[i] = (bf16_t)s;
+    db[i] = (T)s;
   }
 }
 
@@ -348,7 +356,7 @@ inline FwdGeom fwd_geom(int Z, int B, int H, int W, int Ci) {
   return g;
 }
 
-template <int CI, int NT, int MT, int TWX>
+template <typename T, int CI, int NT, int MT, int TWX>
 int launch_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co, int relu,
                int shared_x, hipStream_t st) {
   constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2), G = CI / 8, WSZ = NT * 32 * (G | 1);
@@ -356,21 +364,21 @@ int launch_fwd(const void* x, const void* mask, const void* w, const void* bias,
   static_assert(lds <= 65536, "halo tile + kernel slices exceed 64 KB of LDS");
   const int tiles_w = (int)cdiv(W, TWX), tiles_h = (int)cdiv(H, TH);
   const long plane = (long)B * H * W;
-  hipLaunchKernelGGL((conv3x3_fwd_kernel<CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z), dim3(256), lds, st, (const bf16_t*)x,
-                     (const bf16_t*)mask, (const bf16_t*)w, (const bf16_t*)bias, (bf16_t*)y, H, W, Co, relu, tiles_w,
+  hipLaunchKernelGGL((conv3x3_fwd_kernel<T, CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z), dim3(256), lds, st, (const T*)x,
+                     (const T*)mask, (const T*)w, (const T*)bias, (T*)y, H, W, Co, relu, tiles_w,
                      shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co);
   DGTD_CHECK_LAUNCH("conv3x3_fwd");
   return 0;
 }
 
-template <int CI, int NT>
+template <typename T, int CI, int NT>
 int dispatch_fwd_geom(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co,
                       int relu, int shared_x, hipStream_t st) {
   const FwdGeom g = fwd_geom(Z, B, H, W, CI);
-  if (g.twx == 16) return launch_fwd<CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
-  if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
-  if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
-  return launch_fwd<CI, NT, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+  if (g.twx == 16) return launch_fwd<T, CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+  if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<T, CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
+  if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<T, CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
+  return launch_fwd<T, CI, NT, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
 }
 
 bool supported(int Ci, int Co) {
@@ -378,7 +386,7 @@ bool supported(int Ci, int Co) {
   return ok(Ci) && ok(Co);
 }
 
-template <int CI, int TH, int TW>
+template <typename T, int CI, int TH, int TW>
 int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* ws, int Z, int B, int H, int W, int Co,
                  int shared_x, int P, hipStream_t st) {
   constexpr int CB = (CI + 31) / 32, XS = lds_stride_for(CI), LP = (TH + 2) * (TW + 2);
@@ -388,12 +396,12 @@ int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void
   const long plane = (long)B * H * W;
   float* partial = (float*)ws;
   float* partial_b = partial + (size_t)Z * MTt * P * 32 * 9 * (CB * 32);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), Z), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy,
-                     (const bf16_t*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), Z), dim3(256), lds, st, (const T*)x, (const T*)dy,
+                     (const T*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad");
   const long n = (long)Z * Co * 9 * CI;
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, (const float*)partial,
-                     (const float*)partial_b, (bf16_t*)dw, (bf16_t*)db, Z, Co, CI, CB, MTt, P);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel<T>, dim3((int)cdiv(n, 256)), dim3(256), 0, st, (const float*)partial,
+                     (const float*)partial_b, (T*)dw, (T*)db, Z, Co, CI, CB, MTt, P);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad_reduce");
   return 0;
 }
@@ -414,13 +422,14 @@ inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
 extern "C" int dgtd_conv3x3_supported(int Ci, int Co, int H, int W) { return supported(Ci, Co) && H >= 1 && W >= 16 && W % 16 == 0; }
 
 extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
-                                int Ci, int Co, int relu, int shared_x, dgtd_stream s) {
+                                int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s) {
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad sizes");
+  DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_fwd: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
   DGTD_REQUIRE(!(shared_x && mask), "conv3x3_fwd: a mask needs its own input per convolution");
   hipStream_t st = (hipStream_t)s;
   const int nt = (int)cdiv(Co, 32);
-#define DGTD_CONV_CASE(CI_, NT_) if (Ci == CI_ && nt == NT_) return dispatch_fwd_geom<CI_, NT_>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+#define DGTD_CONV_CASE(CI_, NT_) if (Ci == CI_ && nt == NT_) DGTD_DISPATCH_HALF(dt, return (dispatch_fwd_geom<T_, CI_, NT_>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st)));
   DGTD_CONV_CASE(24, 1) DGTD_CONV_CASE(24, 2) DGTD_CONV_CASE(24, 3)
   DGTD_CONV_CASE(32, 1) DGTD_CONV_CASE(32, 2) DGTD_CONV_CASE(32, 3)
   DGTD_CONV_CASE(64, 1) DGTD_CONV_CASE(64, 2) DGTD_CONV_CASE(64, 3)
@@ -432,7 +441,7 @@ extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, 
 extern "C" int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s) {
   DGTD_REQUIRE(Z > 0 && Co > 0 && Ci > 0, "conv3x3_flip: bad sizes");
   const long n = (long)Z * Co * 9 * Ci;
-  hipLaunchKernelGGL(conv3x3_flip_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)w, (bf16_t*)wt, Co, Ci, n);
+  hipLaunchKernelGGL(conv3x3_flip_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const uint16_t*)w, (uint16_t*)wt, Co, Ci, n);
   DGTD_CHECK_LAUNCH("conv3x3_flip");
   return 0;
 }
@@ -443,14 +452,15 @@ extern "C" int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int 
 }
 
 extern "C" int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
-                                  int H, int W, int Ci, int Co, int shared_x, dgtd_stream s) {
+                                  int H, int W, int Ci, int Co, int shared_x, dgtd_dtype dt, dgtd_stream s) {
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_wgrad: bad sizes");
+  DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_wgrad: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_wgrad: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
   hipStream_t st = (hipStream_t)s;
   const int P = wgrad_splits(Z, B, H, W, Ci, Co);
   const bool wide = W >= 32;
-#define DGTD_WG_CASE(CI_, TH_) if (Ci == CI_) return wide ? launch_wgrad<CI_, TH_, 32>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st) \
-                                                         : launch_wgrad<CI_, TH_, 16>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st);
+#define DGTD_WG_CASE(CI_, TH_) if (Ci == CI_) DGTD_DISPATCH_HALF(dt, return wide ? (launch_wgrad<T_, CI_, TH_, 32>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st)) \
+                                                         : (launch_wgrad<T_, CI_, TH_, 16>(x, dy, mask, dw, db, workspace, Z, B, H, W, Co, shared_x, P, st)));
   DGTD_WG_CASE(24, 8) DGTD_WG_CASE(32, 8) DGTD_WG_CASE(64, 4) DGTD_WG_CASE(96, 4)
 #undef DGTD_WG_CASE
   DGTD_FAIL(2, "conv3x3_wgrad: no kernel for Ci=%d", Ci);

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 template <typename T> struct Pair;
 template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Pair<bf16_t> { typedef bf16_t type __attribute__((ext_vector_type(2))); };
+template <> struct Pair<f16_t> { typedef f16_t type __attribute__((ext_vector_type(2))); };
 
 // ws[gridDim.x][K*K + 1][C] -> out[(K*K + 1) * C] (= { dw_t | db }); fixed summation order, no atomics
 __global__ __launch_bounds__(256) void dwconv_bww_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks,
@@ -318,12 +319,14 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
   DGTD_REQUIRE(mode >= 0 && mode <= 3 && (mode < 2 || aux), "dwconv_fwd: bad mode %d", mode);
   hipStream_t st = (hipStream_t)s;
-  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_fwd: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "dwconv_fwd: bad dtype %d", (int)dt);
   // measured (profiles/r01_ops_device_times.txt): the LDS-tiled kernel wins 1.6-1.8x for 7x7 (49-tap halo reuse); for 3x3 the direct
   // kernel with 16-byte loads is as fast or faster
   if (K == 7 && C % 128 == 0 && use_tiled()) return dgtd_dwconv_tiled_fwd(x, w_t, bias, aux, y, B, H, W, C, K, mode, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
                                      : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  if (dt == DGTD_F16) return K == 7 ? fwd_launch<f16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
+                                    : fwd_launch<f16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   if (dt == DGTD_F32) return K == 7 ? fwd_launch<float, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
                                     : fwd_launch<float, 4, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   DGTD_FAIL(2, "dwconv_fwd: bad dtype %d", (int)dt);
@@ -341,13 +344,15 @@ extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grad
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight: K=%d (only 3 and 7 are on the path)", K);
   hipStream_t st = (hipStream_t)s;
-  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "dwconv_bwd_weight: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "dwconv_bwd_weight: bad dtype %d", (int)dt);
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
   // measured: the K-wave direct kernel below beats the LDS-tiled weight gradient on every shape of the model (its accumulators
   // never leave the wave); the tiled variant stays selectable for experiments
   if (use_tiled() && getenv("DGTD_DWCONV_TILED_BWW")) return dgtd_dwconv_tiled_bww(x, du, grads, has_bias, workspace, B, H, W, C, K, dt, st);
   if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
                                      : bww_launch<bf16_t, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
+  if (dt == DGTD_F16) return K == 7 ? bww_launch<f16_t, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
+                                    : bww_launch<f16_t, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
                                     : bww_launch<float, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   DGTD_FAIL(2, "dwconv_bwd_weight: bad dtype %d", (int)dt);
@@ -357,6 +362,7 @@ extern "C" int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, 
   DGTD_REQUIRE(C > 0 && (K == 3 || K == 7), "dwconv_pack: bad sizes C=%d K=%d", C, K);
   const int KK = K * K, grid = (int)cdiv((int64_t)KK * C, 256);
   if (wdt == DGTD_BF16) hipLaunchKernelGGL(dwconv_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)w, (const bf16_t*)bias, packed, C, KK);
+  else if (wdt == DGTD_F16) hipLaunchKernelGGL(dwconv_pack_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const f16_t*)w, (const f16_t*)bias, packed, C, KK);
   else if (wdt == DGTD_F32) hipLaunchKernelGGL(dwconv_pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)w, (const float*)bias, packed, C, KK);
   else DGTD_FAIL(2, "dwconv_pack: bad dtype %d", (int)wdt);
   DGTD_CHECK_LAUNCH("dwconv_pack");
@@ -367,6 +373,7 @@ extern "C" int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, 
   DGTD_REQUIRE(C > 0 && (K == 3 || K == 7), "dwconv_unpack_grads: bad sizes C=%d K=%d", C, K);
   const int KK = K * K, grid = (int)cdiv((int64_t)KK * C, 256);
   if (wdt == DGTD_BF16) hipLaunchKernelGGL(dwconv_unpack_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, grads, (bf16_t*)dw, (bf16_t*)db, C, KK);
+  else if (wdt == DGTD_F16) hipLaunchKernelGGL(dwconv_unpack_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, grads, (f16_t*)dw, (f16_t*)db, C, KK);
   else if (wdt == DGTD_F32) hipLaunchKernelGGL(dwconv_unpack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, grads, (float*)dw, (float*)db, C, KK);
   else DGTD_FAIL(2, "dwconv_unpack_grads: bad dtype %d", (int)wdt);
   DGTD_CHECK_LAUNCH("dwconv_unpack_grads");

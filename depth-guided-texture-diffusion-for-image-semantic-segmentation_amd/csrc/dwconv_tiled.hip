@@ -20,6 +20,7 @@ __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_grad_fast(x)
 template <typename T> struct Pair2;
 template <> struct Pair2<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Pair2<bf16_t> { typedef bf16_t type __attribute__((ext_vector_type(2))); };
+template <> struct Pair2<f16_t> { typedef f16_t type __attribute__((ext_vector_type(2))); };
 
 // stage rows [y0 - P, y0 + TY + P) x cols [x0 - P, x0 + TXW + P) x channels [cb*128, +128) of image b into LDS, zero padded.
 // All of a thread's 16-byte loads are issued before the first LDS store (fully unrolled, registers), so the tile arrives with
@@ -252,6 +253,7 @@ static int tiled_fwd(const void* x, const float* wt, const float* bias, const vo
 int dgtd_dwconv_tiled_fwd(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C, int K,
                           int mode, dgtd_dtype dt, hipStream_t s) {
   if (dt == DGTD_BF16) return K == 7 ? tiled_fwd<bf16_t, 7>(x, wt, bias, aux, y, B, H, W, C, mode, s) : tiled_fwd<bf16_t, 3>(x, wt, bias, aux, y, B, H, W, C, mode, s);
+  if (dt == DGTD_F16) return K == 7 ? tiled_fwd<f16_t, 7>(x, wt, bias, aux, y, B, H, W, C, mode, s) : tiled_fwd<f16_t, 3>(x, wt, bias, aux, y, B, H, W, C, mode, s);
   return K == 7 ? tiled_fwd<float, 7>(x, wt, bias, aux, y, B, H, W, C, mode, s) : tiled_fwd<float, 3>(x, wt, bias, aux, y, B, H, W, C, mode, s);
 }
 
@@ -272,5 +274,6 @@ static int tiled_bww(const void* x, const void* du, float* grads, int has_bias, 
 int dgtd_dwconv_tiled_bww(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, int K,
                           dgtd_dtype dt, hipStream_t s) {
   if (dt == DGTD_BF16) return K == 7 ? tiled_bww<bf16_t, 7>(x, du, grads, has_bias, workspace, B, H, W, C, s) : tiled_bww<bf16_t, 3>(x, du, grads, has_bias, workspace, B, H, W, C, s);
+  if (dt == DGTD_F16) return K == 7 ? tiled_bww<f16_t, 7>(x, du, grads, has_bias, workspace, B, H, W, C, s) : tiled_bww<f16_t, 3>(x, du, grads, has_bias, workspace, B, H, W, C, s);
   return K == 7 ? tiled_bww<float, 7>(x, du, grads, has_bias, workspace, B, H, W, C, s) : tiled_bww<float, 3>(x, du, grads, has_bias, workspace, B, H, W, C, s);
 }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
   }
 }
 
-// ws [nblocks][C] -> out[C]; one workgroup per 32 columns x 8 row groups, fixed summation order
+// ws [nblocks][C] -> out[C] (out_bf16 = dtype code of out: DGTD_F32 / DGTD_BF16 / DGTD_F16); one workgroup per 32 columns x 8 row groups, fixed summation order
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, void* __restrict__ out, int out_bf16, int nblocks, int C) {
   __shared__ float part[8][32];
   const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v += part[k][lane];
-    if (out_bf16) ((bf16_t*)out)[col] = (bf16_t)v;
+    if (out_bf16 == DGTD_BF16) ((bf16_t*)out)[col] = (bf16_t)v;
+    else if (out_bf16 == DGTD_F16) ((f16_t*)out)[col] = (f16_t)v;
     else ((float*)out)[col] = v;
   }
 }
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void colsum2_reduce_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) v += part[k][lane];
     if (col < C) outA[col] = v;
-    else if (outB_bf16) ((bf16_t*)outB)[col - C] = (bf16_t)v;
+    else if (outB_bf16 == DGTD_BF16) ((bf16_t*)outB)[col - C] = (bf16_t)v;
+    else if (outB_bf16 == DGTD_F16) ((f16_t*)outB)[col - C] = (f16_t)v;
     else ((float*)outB)[col - C] = v;
   }
 }
@@ -264,10 +266,11 @@ int colsum2_launch(const void* g, const void* y, const float* s, const float* ga
 extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out, int64_t rows,
                                        int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
   DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0, "scale_residual_fwd: bad sizes");
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(C % V == 0, "scale_residual_fwd: C=%d must be a multiple of %d", C, V);
   const int grid = (int)std::min<int64_t>(cdiv(rows * (C / V), 256), 256 * 16);
   if (dt == DGTD_BF16) hipLaunchKernelGGL(scale_residual_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const bf16_t*)x, (const bf16_t*)y, s, gamma, (bf16_t*)out, rows, C, rows_per_sample);
+  else if (dt == DGTD_F16) hipLaunchKernelGGL(scale_residual_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const f16_t*)x, (const f16_t*)y, s, gamma, (f16_t*)out, rows, C, rows_per_sample);
   else if (dt == DGTD_F32) hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const float*)x, (const float*)y, s, gamma, (float*)out, rows, C, rows_per_sample);
   else DGTD_FAIL(2, "scale_residual_fwd: bad dtype %d", (int)dt);
   DGTD_CHECK_LAUNCH("scale_residual_fwd");
@@ -283,6 +286,8 @@ extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float
   hipStream_t h = (hipStream_t)st;
   if (dt == DGTD_BF16) return gamma ? colsum_launch<bf16_t, 1>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd")
                                     : colsum_launch<bf16_t, 2>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd");
+  if (dt == DGTD_F16) return gamma ? colsum_launch<f16_t, 1>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd")
+                                   : colsum_launch<f16_t, 2>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd");
   if (dt == DGTD_F32) return gamma ? colsum_launch<float, 1>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd")
                                    : colsum_launch<float, 2>(g, y, s, gamma, dy, dgamma, workspace, rows, C, rows_per_sample, h, "scale_residual_bwd");
   DGTD_FAIL(2, "scale_residual_bwd: bad dtype %d", (int)dt);
@@ -290,9 +295,10 @@ extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float
 
 extern "C" int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
   DGTD_REQUIRE(rows > 0 && C > 0, "colsum: bad sizes");
-  DGTD_REQUIRE(out_dt == DGTD_F32 || out_dt == DGTD_BF16, "colsum: bad output dtype %d", (int)out_dt);
-  const int ob = out_dt == DGTD_BF16;
+  DGTD_REQUIRE(out_dt == DGTD_F32 || DGTD_IS_HALF(out_dt), "colsum: bad output dtype %d", (int)out_dt);
+  const int ob = (int)out_dt;
   if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
+  if (dt == DGTD_F16) return colsum_launch<f16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
   if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, out, workspace, rows, C, 1, (hipStream_t)st, "colsum", ob);
   DGTD_FAIL(2, "colsum: bad dtype %d", (int)dt);
 }
@@ -304,9 +310,10 @@ extern "C" int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const 
                                             int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
   DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0 && dbias, "scale_residual_bias_bwd: bad sizes");
   DGTD_REQUIRE((gamma == nullptr) == (dgamma == nullptr), "scale_residual_bias_bwd: gamma and dgamma go together");
-  DGTD_REQUIRE(bias_dt == DGTD_F32 || bias_dt == DGTD_BF16, "scale_residual_bias_bwd: bad bias dtype %d", (int)bias_dt);
+  DGTD_REQUIRE(bias_dt == DGTD_F32 || DGTD_IS_HALF(bias_dt), "scale_residual_bias_bwd: bad bias dtype %d", (int)bias_dt);
   hipStream_t h = (hipStream_t)st;
-  const int ob = bias_dt == DGTD_BF16;
+  const int ob = (int)bias_dt;
+  if (dt == DGTD_F16) return colsum2_launch<f16_t, 3>(g, y, s, gamma, dy, dgamma, dbias, ob, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd");
   if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 3>(g, y, s, gamma, dy, dgamma, dbias, ob, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd");
   if (dt == DGTD_F32) return colsum2_launch<float, 3>(g, y, s, gamma, dy, dgamma, dbias, ob, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd");
   DGTD_FAIL(2, "scale_residual_bias_bwd: bad dtype %d", (int)dt);
@@ -315,9 +322,10 @@ extern "C" int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const 
 extern "C" int dgtd_gelu_bias_bwd(const void* g, const void* pre, void* dpre, void* dbias, dgtd_dtype bias_dt, void* workspace,
                                   int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
   DGTD_REQUIRE(rows > 0 && C > 0 && dbias, "gelu_bias_bwd: bad sizes");
-  DGTD_REQUIRE(bias_dt == DGTD_F32 || bias_dt == DGTD_BF16, "gelu_bias_bwd: bad bias dtype %d", (int)bias_dt);
+  DGTD_REQUIRE(bias_dt == DGTD_F32 || DGTD_IS_HALF(bias_dt), "gelu_bias_bwd: bad bias dtype %d", (int)bias_dt);
   hipStream_t h = (hipStream_t)st;
-  const int ob = bias_dt == DGTD_BF16;
+  const int ob = (int)bias_dt;
+  if (dt == DGTD_F16) return colsum2_launch<f16_t, 4>(g, pre, nullptr, nullptr, dpre, nullptr, dbias, ob, workspace, rows, C, 1, h, "gelu_bias_bwd");
   if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 4>(g, pre, nullptr, nullptr, dpre, nullptr, dbias, ob, workspace, rows, C, 1, h, "gelu_bias_bwd");
   if (dt == DGTD_F32) return colsum2_launch<float, 4>(g, pre, nullptr, nullptr, dpre, nullptr, dbias, ob, workspace, rows, C, 1, h, "gelu_bias_bwd");
   DGTD_FAIL(2, "gelu_bias_bwd: bad dtype %d", (int)dt);

@@ -289,9 +289,10 @@ inline int ew_grid(int64_t items) { return (int)std::min<int64_t>(cdiv(items, 25
 }  // namespace
 
 extern "C" int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n, dgtd_dtype dt, dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_fwd: n=%lld must be a positive multiple of %d", (long long)n, V);
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_fwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, a, (bf16_t*)y, n);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(prelu_fwd_kernel<f16_t>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, a, (f16_t*)y, n);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_fwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, a, (bf16_t*)y, n);
   else if (dt == DGTD_F32) hipLaunchKernelGGL(prelu_fwd_kernel<float>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const float*)x, a, (float*)y, n);
   else DGTD_FAIL(2, "prelu_fwd: bad dtype %d", (int)dt);
   DGTD_CHECK_LAUNCH("prelu_fwd");
@@ -299,10 +300,11 @@ extern "C" int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n,
 }
 
 extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float* da, int64_t n, dgtd_dtype dt, dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_bwd: n=%lld must be a positive multiple of %d", (long long)n, V);
   const int grid = std::min(ew_grid(n / V), 512);
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)g, a, (bf16_t*)dx, da, n);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(prelu_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, (const f16_t*)g, a, (f16_t*)dx, da, n);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(prelu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)g, a, (bf16_t*)dx, da, n);
   else if (dt == DGTD_F32) hipLaunchKernelGGL(prelu_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)g, a, (float*)dx, da, n);
   else DGTD_FAIL(2, "prelu_bwd: bad dtype %d", (int)dt);
   DGTD_CHECK_LAUNCH("prelu_bwd");
@@ -312,19 +314,21 @@ extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void
 // stats fp32 [B*C (pooled sums) | B*C (gate) | B*R (hidden) | 64*B*C (per-slice partial sums)]: nothing to zero
 extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats, int B, int HW,
                                 int C, int R, dgtd_dtype dt, dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_fwd: unsupported sizes C=%d R=%d", C, R);
-  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C, *partial = hidden + (size_t)B * R;
   const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
-  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
+  if (dt == DGTD_F16) hipLaunchKernelGGL((pooled_sum_kernel<f16_t, false>), dim3(gx, B), dim3(256), 0, st, (const f16_t*)res, (const f16_t*)nullptr, partial, HW, C);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_pooled_sum");
   hipLaunchKernelGGL(ca_gate_mlp_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, pooled, w1, w2, gate, hidden, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp");
   const int64_t rows = (int64_t)B * HW;
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)x, (const float*)gate, (bf16_t*)out, rows, HW, C);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_kernel<f16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const f16_t*)res, (const f16_t*)x, (const float*)gate, (f16_t*)out, rows, HW, C);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)x, (const float*)gate, (bf16_t*)out, rows, HW, C);
   else hipLaunchKernelGGL(ca_apply_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)res, (const float*)x, (const float*)gate, (float*)out, rows, HW, C);
   DGTD_CHECK_LAUNCH("ca_apply");
   return 0;
@@ -333,20 +337,22 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
 // scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums) | B*2*R*C (per-sample dw)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero
 extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                                 float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_bwd: unsupported sizes C=%d R=%d", C, R);
-  DGTD_REQUIRE(dt == DGTD_BF16 || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
   float *dmean = scratch, *partial = scratch + (size_t)B * C, *dwp = partial + (size_t)64 * B * C;
   const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
-  if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
+  if (dt == DGTD_F16) hipLaunchKernelGGL((pooled_sum_kernel<f16_t, true>), dim3(gx, B), dim3(256), 0, st, (const f16_t*)g, (const f16_t*)res, partial, HW, C);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
   hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, gate, hidden, pooled, w1, w2, dmean, dwp, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp_bwd");
   const int64_t rows = (int64_t)B * HW;
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_bwd_kernel<f16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const f16_t*)g, gate, (const float*)dmean, (f16_t*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_kernel<bf16_t>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const bf16_t*)g, gate, (const float*)dmean, (bf16_t*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
   else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
   DGTD_CHECK_LAUNCH("ca_apply_bwd");
   return 0;
@@ -354,11 +360,12 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
 
 extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
                                  dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_fwd: bad sizes (C=%d must be a multiple of %d)", C, V);
   const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);
   const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(bilinear_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, (f16_t*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
   else if (dt == DGTD_F32) hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, B, Hi, Wi, Ho, Wo, C, ah, aw);
   else DGTD_FAIL(2, "bilinear_fwd: bad dtype %d", (int)dt);
   DGTD_CHECK_LAUNCH("bilinear_fwd");
@@ -367,13 +374,14 @@ extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, 
 
 extern "C" int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
                                  dgtd_stream s) {
-  const int V = dt == DGTD_BF16 ? 8 : 4;
+  const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_bwd: bad sizes (C=%d must be a multiple of %d)", C, V);
   const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);
   // d(src)/d(out index) = scale, so an input pixel i is touched by outputs around i / scale
   const float inv_h = ah.scale > 0.f ? 1.f / ah.scale : (float)Ho, inv_w = aw.scale > 0.f ? 1.f / aw.scale : (float)Wo;
   const int grid = ew_grid((int64_t)B * Hi * Wi * (C / V));
-  if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
+  if (dt == DGTD_F16) hipLaunchKernelGGL(bilinear_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const f16_t*)dy, (f16_t*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
+  else if (dt == DGTD_BF16) hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
   else if (dt == DGTD_F32) hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, B, Hi, Wi, Ho, Wo, C, ah, aw, inv_h, inv_w);
   else DGTD_FAIL(2, "bilinear_bwd: bad dtype %d", (int)dt);
   DGTD_CHECK_LAUNCH("bilinear_bwd");

@@ -290,6 +290,7 @@ extern "C" int dgtd_layernorm_fwd(const void* x, const float* gamma, const float
                                   int64_t rows, int C, float eps, dgtd_dtype dt, dgtd_stream s) {
   if (dt == DGTD_F32) return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   if (dt == DGTD_BF16) return ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
+  if (dt == DGTD_F16) return ln_fwd_launch<f16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   DGTD_FAIL(2, "layernorm_fwd: bad dtype %d", (int)dt);
 }
 
@@ -298,6 +299,7 @@ extern "C" int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float
                                       dgtd_dtype dt, dgtd_stream s) {
   if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
+  if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   DGTD_FAIL(2, "layernorm_bwd_add: bad dtype %d", (int)dt);
 }
 
@@ -308,5 +310,6 @@ extern "C" int dgtd_layernorm_bwd(const void* dy, const void* x, const float* ga
                                   dgtd_dtype dt, dgtd_stream s) {
   if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);
   if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);
+  if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);
   DGTD_FAIL(2, "layernorm_bwd: bad dtype %d", (int)dt);
 }

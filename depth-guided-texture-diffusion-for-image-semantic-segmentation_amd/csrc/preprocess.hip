@@ -113,7 +113,7 @@ extern "C" int dgtd_preprocess(const void* img_u8, void* out, const float* mean_
                                int Win, int C, int S, int flip, dgtd_dtype out_dt, dgtd_stream s) {
   DGTD_REQUIRE(Hin > 0 && Win > 0 && S > 0 && C >= 1 && C <= 4, "preprocess: bad sizes H=%d W=%d C=%d S=%d", Hin, Win, C, S);
   DGTD_REQUIRE((mean_host == nullptr) == (std_host == nullptr), "preprocess: mean and std go together");
-  DGTD_REQUIRE(out_dt == DGTD_F32 || out_dt == DGTD_BF16, "preprocess: bad output dtype %d", (int)out_dt);
+  DGTD_REQUIRE(out_dt == DGTD_F32 || DGTD_IS_HALF(out_dt), "preprocess: bad output dtype %d", (int)out_dt);
   hipStream_t st = (hipStream_t)s;
   const int kh = ksize_for(Win, S), kv = ksize_for(Hin, S);
   uint8_t* mid = (uint8_t*)workspace;
@@ -132,6 +132,7 @@ extern "C" int dgtd_preprocess(const void* img_u8, void* out, const float* mean_
   DGTD_CHECK_LAUNCH("preprocess_horizontal");
   const int gv = (int)std::min<int64_t>(cdiv((int64_t)S * S, 256), 4096);
   if (out_dt == DGTD_F32) hipLaunchKernelGGL(resize_v_norm_kernel<float>, dim3(gv), dim3(256), 0, st, (const uint8_t*)mid, (float*)out, (const int*)bounds_v, (const int*)kk_v, Hin, C, S, kv, na);
+  else if (out_dt == DGTD_F16) hipLaunchKernelGGL(resize_v_norm_kernel<f16_t>, dim3(gv), dim3(256), 0, st, (const uint8_t*)mid, (f16_t*)out, (const int*)bounds_v, (const int*)kk_v, Hin, C, S, kv, na);
   else hipLaunchKernelGGL(resize_v_norm_kernel<bf16_t>, dim3(gv), dim3(256), 0, st, (const uint8_t*)mid, (bf16_t*)out, (const int*)bounds_v, (const int*)kk_v, Hin, C, S, kv, na);
   DGTD_CHECK_LAUNCH("preprocess_vertical");
   return 0;

@@ -21,12 +21,17 @@ inline void* stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); 
 inline dgtd_dtype code(const Tensor& t) {
   if (t.scalar_type() == at::kFloat) return DGTD_F32;
   if (t.scalar_type() == at::kBFloat16) return DGTD_BF16;
-  TORCH_CHECK(false, "dgtd kernels take float32 or bfloat16 tensors, got ", t.scalar_type());
+  if (t.scalar_type() == at::kHalf) return DGTD_F16;
+  TORCH_CHECK(false, "dgtd kernels take float32, bfloat16 or float16 tensors, got ", t.scalar_type());
 }
 inline void check(int rc, const char* name) { TORCH_CHECK(rc == 0, name, " failed (code ", rc, "): ", dgtd_last_error()); }
 inline void on_device(const Tensor& t) { TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "dgtd ops need contiguous tensors on the HIP device"); }
 inline Tensor f32(const Tensor& t) { return t.scalar_type() == at::kFloat ? t.contiguous() : t.to(at::kFloat).contiguous(); }
 inline Tensor undefined() { return Tensor(); }
+inline bool is16(at::ScalarType t) { return t == at::kBFloat16 || t == at::kHalf; }
+inline at::ScalarType from_code(int64_t dt_code) { return dt_code == DGTD_BF16 ? at::kBFloat16 : (dt_code == DGTD_F16 ? at::kHalf : at::kFloat); }
+inline int64_t st_id(const Tensor& t) { return (int64_t)t.scalar_type(); }                  // a dtype remembered across forward -> backward
+inline at::ScalarType st_of(const c10::IValue& v) { return (at::ScalarType)v.toInt(); }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
@@ -152,7 +157,7 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     ctx->saved_data["gelu"] = gelu;
     ctx->saved_data["K"] = K;
     ctx->saved_data["has_bias"] = has_bias;
-    ctx->saved_data["bf16_w"] = weight.scalar_type() == at::kBFloat16;
+    ctx->saved_data["w_dt"] = st_id(weight);
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -160,7 +165,7 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     const Tensor &x = saved[0], &packed = saved[1];
     const bool gelu = ctx->saved_data["gelu"].toBool(), has_bias = ctx->saved_data["has_bias"].toBool();
     const int64_t K = ctx->saved_data["K"].toInt(), KK = K * K, C = x.size(3);
-    const auto wdtype = ctx->saved_data["bf16_w"].toBool() ? at::kBFloat16 : at::kFloat;
+    const auto wdtype = st_of(ctx->saved_data["w_dt"]);
     Tensor dy = g[0].contiguous();
     if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
     const float* base = packed.data_ptr<float>();
@@ -198,7 +203,7 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     ctx->save_for_backward({x, packed});
     ctx->saved_data["K"] = K;
     ctx->saved_data["has_bias"] = has_bias;
-    ctx->saved_data["bf16_w"] = weight.scalar_type() == at::kBFloat16;
+    ctx->saved_data["w_dt"] = st_id(weight);
     return {y, x_};
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -206,7 +211,7 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     const Tensor &x = saved[0], &packed = saved[1];
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
     const int64_t K = ctx->saved_data["K"].toInt(), KK = K * K, C = x.size(3);
-    const auto wdtype = ctx->saved_data["bf16_w"].toBool() ? at::kBFloat16 : at::kFloat;
+    const auto wdtype = st_of(ctx->saved_data["w_dt"]);
     Tensor skip;
     if (g[1].defined()) skip = (g[1].scalar_type() == x.scalar_type() ? g[1] : g[1].to(x.scalar_type())).contiguous();
     if (!g[0].defined()) return {skip, undefined(), undefined()};
@@ -241,7 +246,7 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
     ctx->save_for_backward({y, s, g32});
     ctx->saved_data["has_s"] = has_s;
     ctx->saved_data["has_g"] = has_g;
-    ctx->saved_data["bf16_g"] = has_g && gamma_->scalar_type() == at::kBFloat16;
+    ctx->saved_data["g_dt"] = has_g ? st_id(*gamma_) : (int64_t)at::kFloat;
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -258,7 +263,7 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
     check(dgtd_scale_residual_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
                                   dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, has_g ? ws.data_ptr() : nullptr, rows, (int)C,
                                   rows / B, code(y), stream()), "dgtd_scale_residual_bwd");
-    if (has_g && ctx->saved_data["bf16_g"].toBool()) dgamma = dgamma.to(at::kBFloat16);
+    if (has_g && st_of(ctx->saved_data["g_dt"]) != at::kFloat) dgamma = dgamma.to(st_of(ctx->saved_data["g_dt"]));
     return {g, dy, undefined(), dgamma};
   }
 };
@@ -273,12 +278,12 @@ Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
   return out;
 }
 
-// GEMM helpers shared by the Linear nodes: bf16 goes to hipBLASLt with cached plans (gemm.h), anything else to ATen.
+// GEMM helpers shared by the Linear nodes: bf16 / fp16 go to hipBLASLt with cached plans (gemm.h), anything else to ATen.
 inline Tensor gemm_fwd(const Tensor& x2, const Tensor& wc, const Tensor& bc, Tensor o2 = Tensor()) {   // [M,K] x [N,K]^T (+ bias[N]) -> [M,N]
   const int64_t M = x2.size(0), K = x2.size(1), N = wc.size(0);
   if (!o2.defined()) o2 = at::empty({M, N}, x2.options());
-  const bool direct = x2.scalar_type() == at::kBFloat16 && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
-                      dgemm::matmul_bf16(x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), bc.defined() ? bc.data_ptr() : nullptr, M, N, K, false,
+  const bool direct = is16(x2.scalar_type()) && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
+                      dgemm::matmul_16(x2.scalar_type(), x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), bc.defined() ? bc.data_ptr() : nullptr, M, N, K, false,
                                          true, 1, 0, 0, 0, x2.options(), (hipStream_t)stream());
   if (!direct) {
     if (bc.defined()) at::addmm_out(o2, bc, x2, wc.t());
@@ -289,8 +294,8 @@ inline Tensor gemm_fwd(const Tensor& x2, const Tensor& wc, const Tensor& bc, Ten
 inline Tensor gemm_dx(const Tensor& dy2, const Tensor& wc) {                              // [M,N] x [N,K] -> [M,K]
   const int64_t M = dy2.size(0), N = wc.size(0), K = wc.size(1);
   Tensor dx2 = at::empty({M, K}, dy2.options());
-  const bool bf = dy2.scalar_type() == at::kBFloat16 && wc.is_contiguous() && M > 0;
-  if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, M, K, N, false, false, 1, 0, 0, 0, dy2.options(),
+  const bool bf = is16(dy2.scalar_type()) && wc.is_contiguous() && M > 0;
+  if (!(bf && dgemm::matmul_16(dy2.scalar_type(), dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, M, K, N, false, false, 1, 0, 0, 0, dy2.options(),
                                  (hipStream_t)stream())))
     at::mm_out(dx2, dy2, wc);
   return dx2;
@@ -299,19 +304,19 @@ inline Tensor gemm_dx(const Tensor& dy2, const Tensor& wc) {                    
 // few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
 inline Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                              // [M,N]^T x [M,K] -> [N,K]
   const int64_t M = dy2.size(0), N = dy2.size(1), K = x2.size(1);
-  const bool bf = dy2.scalar_type() == at::kBFloat16 && x2.is_contiguous() && M > 0;
+  const bool bf = is16(dy2.scalar_type()) && x2.is_contiguous() && M > 0;
   hipStream_t st = (hipStream_t)stream();
   static const int64_t max_split = [] { const char* e = std::getenv("DGTD_WGRAD_SPLIT"); return e ? (int64_t)std::atol(e) : (int64_t)32; }();
   const int64_t S = std::min<int64_t>(max_split, M / 1024);
-  if (S >= 4 && M % S == 0 && dy2.scalar_type() == at::kBFloat16) {
+  if (S >= 4 && M % S == 0 && is16(dy2.scalar_type())) {
     Tensor part = at::empty({S, N, K}, dy2.options());
-    if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, N, K, M / S, true, false, (int)S, (M / S) * N,
+    if (!(bf && dgemm::matmul_16(dy2.scalar_type(), dy2.data_ptr(), x2.data_ptr(), part.data_ptr(), nullptr, N, K, M / S, true, false, (int)S, (M / S) * N,
                                    (M / S) * K, N * K, dy2.options(), st)))
       at::bmm_out(part, dy2.view({S, M / S, -1}).transpose(1, 2), x2.view({S, M / S, -1}));
     return at::sum(part, {0});   // bf16 in, fp32 accumulation inside the reduction, bf16 out: one launch
   }
   Tensor dw = at::empty({N, K}, dy2.options());
-  if (!(bf && dgemm::matmul_bf16(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, N, K, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
+  if (!(bf && dgemm::matmul_16(dy2.scalar_type(), dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, N, K, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
     at::mm_out(dw, dy2.t(), x2);
   return dw;
 }
@@ -329,7 +334,7 @@ inline std::vector<int64_t> with_last(const Tensor& x, int64_t n) {
 struct LinearFn : public torch::autograd::Function<LinearFn> {
   // compute dtype `dt` is decided by the caller (autocast policy lives in Python)
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b_, int64_t dt_code) {
-    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    const auto dt = from_code(dt_code);
     const bool has_b = b_.has_value() && b_->defined();
     Tensor x2 = as_rows(x, dt);
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
@@ -341,8 +346,8 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     gemm_fwd(x2, wc, bc, out.view({-1, w.size(0)}));
     ctx->save_for_backward({x2, wc});
     ctx->saved_data["xshape"] = x.sizes().vec();
-    ctx->saved_data["w_bf16"] = w.scalar_type() == at::kBFloat16;
-    ctx->saved_data["b_kind"] = has_b ? (b_->scalar_type() == at::kBFloat16 ? 2 : 1) : 0;
+    ctx->saved_data["w_dt"] = st_id(w);
+    ctx->saved_data["b_dt"] = has_b ? st_id(*b_) : (int64_t)-1;
     ctx->saved_data["need_dx"] = x.requires_grad();
     return out;
   }
@@ -353,11 +358,11 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dy2, wc).view(ctx->saved_data["xshape"].toIntVector());
     Tensor dw = gemm_dw(dy2, x2);
-    const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
-    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
+    const auto w_dt = st_of(ctx->saved_data["w_dt"]);
+    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
     Tensor db;
-    const int64_t bk = ctx->saved_data["b_kind"].toInt();
-    if (bk) db = colsum(dy2, bk == 2 ? at::kBFloat16 : at::kFloat);
+    const int64_t bk = ctx->saved_data["b_dt"].toInt();
+    if (bk >= 0) db = colsum(dy2, (at::ScalarType)bk);
     return {dx, dw, db, undefined()};
   }
 };
@@ -366,7 +371,7 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
 // and the bias gradient sum(dpre) in one pass (dgtd_gelu_bias_bwd) instead of GELU-backward + column-sum + reduce.
 struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const Tensor& b, int64_t dt_code) {
-    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    const auto dt = from_code(dt_code);
     Tensor x2 = as_rows(x, dt);
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
     Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
@@ -376,8 +381,8 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     at::gelu_out(h2, pre);
     ctx->save_for_backward({x2, wc, pre});
     ctx->saved_data["xshape"] = x.sizes().vec();
-    ctx->saved_data["w_bf16"] = w.scalar_type() == at::kBFloat16;
-    ctx->saved_data["b_bf16"] = b.scalar_type() == at::kBFloat16;
+    ctx->saved_data["w_dt"] = st_id(w);
+    ctx->saved_data["b_dt"] = st_id(b);
     ctx->saved_data["need_dx"] = x.requires_grad();
     return h;
   }
@@ -386,16 +391,15 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     const Tensor &x2 = saved[0], &wc = saved[1], &pre = saved[2];
     Tensor dh = as_rows(g[0], pre.scalar_type());
     const int64_t rows = pre.size(0), C = pre.size(1);
-    const bool b_bf16 = ctx->saved_data["b_bf16"].toBool();
-    Tensor dpre = at::empty_like(pre), db = at::empty({C}, pre.options().dtype(b_bf16 ? at::kBFloat16 : at::kFloat));
+    Tensor dpre = at::empty_like(pre), db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, pre.options().dtype(at::kByte));
     check(dgtd_gelu_bias_bwd(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), code(db), ws.data_ptr(), rows, (int)C, code(pre),
                              stream()), "dgtd_gelu_bias_bwd");
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
     Tensor dw = gemm_dw(dpre, x2);
-    const bool w_bf16 = ctx->saved_data["w_bf16"].toBool();
-    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
+    const auto w_dt = st_of(ctx->saved_data["w_dt"]);
+    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
     return {dx, dw, db, undefined()};
   }
 };
@@ -406,7 +410,7 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
 struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& h, const Tensor& w, const Tensor& b, const Tensor& x_, const c10::optional<Tensor>& s_,
                         const c10::optional<Tensor>& gamma_, int64_t dt_code) {
-    const auto dt = dt_code == 1 ? at::kBFloat16 : at::kFloat;
+    const auto dt = from_code(dt_code);
     const bool has_s = s_.has_value() && s_->defined(), has_g = gamma_.has_value() && gamma_->defined();
     Tensor h2 = as_rows(h, dt);
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
@@ -420,19 +424,20 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
                                   out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
     ctx->save_for_backward({h2, wc, y, s, g32});
     ctx->saved_data["hshape"] = h.sizes().vec();
-    ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, w.scalar_type() == at::kBFloat16, b.scalar_type() == at::kBFloat16,
-                                                   has_g && gamma_->scalar_type() == at::kBFloat16, h.requires_grad(), B};
+    ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, st_id(w), st_id(b), has_g ? st_id(*gamma_) : (int64_t)at::kFloat,
+                                                   h.requires_grad(), B};
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
     auto saved = ctx->get_saved_variables();
     const Tensor &h2 = saved[0], &wc = saved[1], &y = saved[2], &s = saved[3], &g32 = saved[4];
     const auto m = ctx->saved_data["meta"].toIntVector();
-    const bool has_s = m[0], has_g = m[1], w_bf16 = m[2], b_bf16 = m[3], g_bf16 = m[4], need_dh = m[5];
+    const bool has_s = m[0], has_g = m[1], need_dh = m[5];
+    const auto w_dt = (at::ScalarType)m[2], b_dt = (at::ScalarType)m[3], g_dt = (at::ScalarType)m[4];
     Tensor g = gr[0].contiguous();
     if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
     const int64_t rows = y.size(0), C = y.size(1), B = m[6];
-    Tensor dy = at::empty_like(y), db = at::empty({C}, y.options().dtype(b_bf16 ? at::kBFloat16 : at::kFloat));
+    Tensor dy = at::empty_like(y), db = at::empty({C}, y.options().dtype(b_dt));
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, y.options().dtype(at::kByte));
     check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
@@ -441,8 +446,8 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     Tensor dh;
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
     Tensor dw = gemm_dw(dy, h2);
-    if ((dw.scalar_type() == at::kBFloat16) != w_bf16) dw = dw.to(w_bf16 ? at::kBFloat16 : at::kFloat);
-    if (has_g && g_bf16) dgamma = dgamma.to(at::kBFloat16);
+    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    if (has_g && g_dt != at::kFloat) dgamma = dgamma.to(g_dt);
     return {dh, dw, db, g, undefined(), dgamma, undefined()};
   }
 };
@@ -457,26 +462,26 @@ inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor&
   if (need_dx) {
     Tensor wt = at::empty({g.Z, g.Ci, 3, 3, g.Co}, w.options());
     check(dgtd_conv3x3_flip(w.data_ptr(), wt.data_ptr(), g.Z, g.Co, g.Ci, stream()), "dgtd_conv3x3_flip");
-    check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, stream()),
+    check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, code(dy), stream()),
           "dgtd_conv3x3_fwd (input gradient)");
   }
   Tensor ws = at::empty({dgtd_conv3x3_wgrad_workspace(g.Z, g.B, g.H, g.W, g.Ci, g.Co)}, x.options().dtype(at::kByte));
   check(dgtd_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), mask, dw.data_ptr(), has_b ? db.data_ptr() : nullptr, ws.data_ptr(), g.Z, g.B, g.H,
-                           g.W, g.Ci, g.Co, g.shared ? 1 : 0, stream()), "dgtd_conv3x3_wgrad");
+                           g.W, g.Ci, g.Co, g.shared ? 1 : 0, code(x), stream()), "dgtd_conv3x3_wgrad");
 }
 
 struct Conv3x3Fn : public torch::autograd::Function<Conv3x3Fn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w_, const c10::optional<Tensor>& b_, bool relu) {
     Tensor x = x_.contiguous(), w = w_.contiguous();
     on_device(x);
-    TORCH_CHECK(x.dim() == 5 && w.dim() == 5 && x.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16,
-                "dgtd conv3x3 takes bf16 x [Z|1,B,H,W,Ci] and w [Z,Co,3,3,Ci]");
+    TORCH_CHECK(x.dim() == 5 && w.dim() == 5 && is16(x.scalar_type()) && w.scalar_type() == x.scalar_type(),
+                "dgtd conv3x3 takes bf16 or fp16 x [Z|1,B,H,W,Ci] and w [Z,Co,3,3,Ci] of one dtype");
     const bool has_b = b_.has_value() && b_->defined();
     ConvGeom g{(int)w.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)w.size(4), (int)w.size(1), x.size(0) == 1 && w.size(0) > 1};
     Tensor b = has_b ? b_->contiguous() : Tensor();
     Tensor y = at::empty({g.Z, g.B, g.H, g.W, g.Co}, x.options());
     check(dgtd_conv3x3_fwd(x.data_ptr(), nullptr, w.data_ptr(), has_b ? b.data_ptr() : nullptr, y.data_ptr(), g.Z, g.B, g.H, g.W, g.Ci, g.Co,
-                           relu ? 1 : 0, g.shared ? 1 : 0, stream()), "dgtd_conv3x3_fwd");
+                           relu ? 1 : 0, g.shared ? 1 : 0, code(x), stream()), "dgtd_conv3x3_fwd");
     ctx->save_for_backward({x, w, relu ? y : Tensor()});
     ctx->saved_data["has_b"] = has_b;
     ctx->saved_data["need_dx"] = x_.requires_grad();
@@ -487,7 +492,7 @@ struct Conv3x3Fn : public torch::autograd::Function<Conv3x3Fn> {
     const Tensor &x = saved[0], &w = saved[1], &ym = saved[2];
     const bool has_b = ctx->saved_data["has_b"].toBool(), need_dx = ctx->saved_data["need_dx"].toBool();
     ConvGeom g{(int)w.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)w.size(4), (int)w.size(1), x.size(0) == 1 && w.size(0) > 1};
-    Tensor dy = gr[0].contiguous();
+    Tensor dy = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous();
     Tensor dx = need_dx ? at::empty({g.Z, g.B, g.H, g.W, g.Ci}, x.options()) : Tensor();
     Tensor dw = at::empty_like(w), db = has_b ? at::empty({g.Z, g.Co}, w.options()) : Tensor();
     conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db);
@@ -501,13 +506,13 @@ struct Conv3x3Fn : public torch::autograd::Function<Conv3x3Fn> {
 struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w_, const c10::optional<Tensor>& b_, bool relu) {
     Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast), w = w_.contiguous(at::MemoryFormat::ChannelsLast);
-    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16, "dgtd conv3x3 takes bf16 tensors on the HIP device");
+    TORCH_CHECK(x.is_cuda() && is16(x.scalar_type()) && w.scalar_type() == x.scalar_type(), "dgtd conv3x3 takes bf16 or fp16 tensors (one dtype) on the HIP device");
     const bool has_b = b_.has_value() && b_->defined();
     ConvGeom g{1, (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)w.size(1), (int)w.size(0), false};
     Tensor b = has_b ? b_->contiguous() : Tensor();
     Tensor y = at::empty({g.B, g.Co, g.H, g.W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
     check(dgtd_conv3x3_fwd(x.data_ptr(), nullptr, w.data_ptr(), has_b ? b.data_ptr() : nullptr, y.data_ptr(), 1, g.B, g.H, g.W, g.Ci, g.Co,
-                           relu ? 1 : 0, 0, stream()), "dgtd_conv3x3_fwd");
+                           relu ? 1 : 0, 0, code(x), stream()), "dgtd_conv3x3_fwd");
     ctx->save_for_backward({x, w, relu ? y : Tensor()});
     ctx->saved_data["has_b"] = has_b;
     ctx->saved_data["need_dx"] = x_.requires_grad();
@@ -518,7 +523,7 @@ struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
     const Tensor &x = saved[0], &w = saved[1], &ym = saved[2];
     const bool has_b = ctx->saved_data["has_b"].toBool(), need_dx = ctx->saved_data["need_dx"].toBool();
     ConvGeom g{1, (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)w.size(1), (int)w.size(0), false};
-    Tensor dy = gr[0].contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dy = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dx = need_dx ? at::empty_like(x) : Tensor();
     Tensor dw = at::empty_like(w), db = has_b ? at::empty({g.Co}, w.options()) : Tensor();
     conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db);
@@ -537,7 +542,7 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     Tensor y = at::empty_like(x);
     check(dgtd_prelu_fwd(x.data_ptr(), a32.data_ptr<float>(), y.data_ptr(), x.numel(), code(x), stream()), "dgtd_prelu_fwd");
     ctx->save_for_backward({x, a32});
-    ctx->saved_data["a_bf16"] = a.scalar_type() == at::kBFloat16;
+    ctx->saved_data["a_dt"] = st_id(a);
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -549,7 +554,7 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     Tensor da = at::zeros({1}, x.options().dtype(at::kFloat));
     check(dgtd_prelu_bwd(x.data_ptr(), g.data_ptr(), a32.data_ptr<float>(), dx.data_ptr(), da.data_ptr<float>(), x.numel(), code(x), stream()),
           "dgtd_prelu_bwd");
-    if (ctx->saved_data["a_bf16"].toBool()) da = da.to(at::kBFloat16);
+    if (st_of(ctx->saved_data["a_dt"]) != at::kFloat) da = da.to(st_of(ctx->saved_data["a_dt"]));
     return {dx, da};
   }
 };
@@ -566,7 +571,7 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
     check(dgtd_ca_gate_fwd(res.data_ptr(), x.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), out.data_ptr(), stats.data_ptr<float>(),
                            (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_fwd");
     ctx->save_for_backward({res, w1f, w2f, stats});
-    ctx->saved_data["w_bf16"] = w1.scalar_type() == at::kBFloat16;
+    ctx->saved_data["w_dt"] = st_id(w1);
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -580,7 +585,7 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
     check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(),
                            sp, sp + R * C, sp + 2 * R * C, (int)B, (int)HW, (int)C, (int)R, code(res), stream()), "dgtd_ca_gate_bwd");
     Tensor dw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1}), dw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});
-    if (ctx->saved_data["w_bf16"].toBool()) { dw1 = dw1.to(at::kBFloat16); dw2 = dw2.to(at::kBFloat16); }
+    if (st_of(ctx->saved_data["w_dt"]) != at::kFloat) { dw1 = dw1.to(st_of(ctx->saved_data["w_dt"])); dw2 = dw2.to(st_of(ctx->saved_data["w_dt"])); }
     return {dres, g, dw1, dw2};
   }
 };
@@ -593,12 +598,12 @@ struct BilinearFn : public torch::autograd::Function<BilinearFn> {
     Tensor y = at::empty({B, C, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
     check(dgtd_bilinear_fwd(x.data_ptr(), y.data_ptr(), (int)B, (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, align ? 1 : 0, code(x), stream()),
           "dgtd_bilinear_fwd");
-    ctx->saved_data["geom"] = std::vector<int64_t>{B, C, Hi, Wi, Ho, Wo, align ? 1 : 0, x.scalar_type() == at::kBFloat16 ? 1 : 0};
+    ctx->saved_data["geom"] = std::vector<int64_t>{B, C, Hi, Wi, Ho, Wo, align ? 1 : 0, st_id(x)};
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
     const auto q = ctx->saved_data["geom"].toIntVector();
-    const auto dt = q[7] ? at::kBFloat16 : at::kFloat;
+    const auto dt = (at::ScalarType)q[7];
     Tensor g = (gr[0].scalar_type() == dt ? gr[0] : gr[0].to(dt)).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dx = at::empty({q[0], q[1], q[2], q[3]}, g.options().memory_format(at::MemoryFormat::ChannelsLast));
     check(dgtd_bilinear_bwd(g.data_ptr(), dx.data_ptr(), (int)q[0], (int)q[2], (int)q[3], (int)q[4], (int)q[5], (int)q[1], (int)q[6], code(g), stream()),

@@ -1,4 +1,4 @@
-// gemm.h — bf16 GEMMs of the Linear layers through hipBLASLt with CACHED plans.
+// gemm.h — bf16 / fp16 GEMMs of the Linear layers through hipBLASLt with CACHED plans.
 // at::mm / at::addmm re-create the matmul descriptor and re-run hipblasLtMatmulAlgoGetHeuristic on every call (18.5 us of host
 // time per GEMM, tools/host_call_cost.py; 543 GEMMs per training step).  Here a plan (descriptor, layouts, heuristic algorithm)
 // is built once per (shape, transposes, epilogue, batch) and per thread (forward runs on the Python thread, backward on autograd's
@@ -15,16 +15,16 @@ namespace dgemm {
 
 struct Key {
   int64_t m, n, k, sa, sb, sd;
-  int ta, tb, bias, batch;
+  int ta, tb, bias, batch, dtype;
   bool operator==(const Key& o) const {
     return m == o.m && n == o.n && k == o.k && sa == o.sa && sb == o.sb && sd == o.sd && ta == o.ta && tb == o.tb && bias == o.bias &&
-           batch == o.batch;
+           batch == o.batch && dtype == o.dtype;
   }
 };
 struct KeyHash {
   size_t operator()(const Key& k) const {
     size_t h = 1469598103934665603ull;
-    for (int64_t v : {k.m, k.n, k.k, k.sa, k.sb, k.sd, (int64_t)k.ta, (int64_t)k.tb, (int64_t)k.bias, (int64_t)k.batch}) {
+    for (int64_t v : {k.m, k.n, k.k, k.sa, k.sb, k.sd, (int64_t)k.ta, (int64_t)k.tb, (int64_t)k.bias, (int64_t)k.batch, (int64_t)k.dtype}) {
       h ^= (size_t)v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
     }
     return h;
@@ -67,11 +67,12 @@ inline void set_batch(hipblasLtMatrixLayout_t l, int32_t batch, int64_t stride) 
   hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &stride, sizeof(stride));
 }
 
-// D[batch][M][N] (row-major) = op(A) op(B) (+ bias[N]);  A is [M,K] (transA: [K,M]), B is [K,N] (transB: [N,K]), all bf16, dense.
+// D[batch][M][N] (row-major) = op(A) op(B) (+ bias[N]);  A is [M,K] (transA: [K,M]), B is [K,N] (transB: [N,K]), all of the 16-bit type `half_type` (at::kBFloat16 or at::kHalf), dense.
 // Returns false when hipBLASLt offers no algorithm for the problem: the caller then uses the ATen GEMM.
-inline bool matmul_bf16(const void* A, const void* B, void* D, const void* bias, int64_t M, int64_t N, int64_t K, bool transA,
-                        bool transB, int batch, int64_t sA, int64_t sB, int64_t sD, const at::TensorOptions& dev_opts, hipStream_t st) {
+inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, void* D, const void* bias, int64_t M, int64_t N, int64_t K,
+                      bool transA, bool transB, int batch, int64_t sA, int64_t sB, int64_t sD, const at::TensorOptions& dev_opts, hipStream_t st) {
   if (!enabled()) return false;
+  const hipDataType DT = half_type == at::kHalf ? HIP_R_16F : HIP_R_16BF;
   Ctx& c = ctx();
   if (c.dead) return false;
   if (!c.handle) {
@@ -83,7 +84,7 @@ inline bool matmul_bf16(const void* A, const void* B, void* D, const void* bias,
     }
     c.ws = at::empty({(int64_t)kWorkspace}, dev_opts.dtype(at::kByte));
   }
-  const Key key{M, N, K, sA, sB, sD, (int)transA, (int)transB, bias ? 1 : 0, batch};
+  const Key key{M, N, K, sA, sB, sD, (int)transA, (int)transB, bias ? 1 : 0, batch, (int)DT};
   auto it = c.plans.find(key);
   if (it == c.plans.end()) {
     Plan p;
@@ -94,14 +95,14 @@ inline bool matmul_bf16(const void* A, const void* B, void* D, const void* bias,
     good = good && ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opB, sizeof(int32_t)));
     if (good && bias) {
       const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
-      const int32_t bt = (int32_t)HIP_R_16BF;
+      const int32_t bt = (int32_t)DT;
       good = ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi))) &&
              ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt))) &&
              ok(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(void*)));
     }
-    good = good && ok(transB ? hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, K, N, K) : hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, N, K, N));
-    good = good && ok(transA ? hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, M, K, M) : hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, K, M, K));
-    good = good && ok(hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, N, M, N));
+    good = good && ok(transB ? hipblasLtMatrixLayoutCreate(&p.a, DT, K, N, K) : hipblasLtMatrixLayoutCreate(&p.a, DT, N, K, N));
+    good = good && ok(transA ? hipblasLtMatrixLayoutCreate(&p.b, DT, M, K, M) : hipblasLtMatrixLayoutCreate(&p.b, DT, K, M, K));
+    good = good && ok(hipblasLtMatrixLayoutCreate(&p.d, DT, N, M, N));
     if (good && batch > 1) {
       set_batch(p.a, batch, sB);
       set_batch(p.b, batch, sA);

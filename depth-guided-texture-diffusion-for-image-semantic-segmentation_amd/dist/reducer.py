@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 # constructed but never called in the reference forward (cod.py:703-704, :1251): no gradient, ever
 STATIC_UNUSED = ("hitnet.backbone.prompt_encoder.adaptor.", "hitnet.ca.", "hitnet.sa.")
+ALIGN = 8   # elements: every tensor of a bucket starts on a 16-byte (2-byte dtypes) / 32-byte (fp32) boundary
 
 
 def init_process_group(backend: Optional[str] = None) -> tuple:
@@ -101,24 +102,29 @@ class GradReducer:
         self.overlap = overlap and (self.world > 1 or self._force)
         self._cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self._cuda and self.overlap) else None
-        self._works = []
+        self._works, self._next = [], 0
         for b in self.buckets:
             for leaf in b["leaves"]:
                 leaf.register_post_accumulate_grad_hook(self._make_hook(b))
+        self._install_load_hooks()
         self.refresh_working()
 
     # ------------------------------------------------------------------ construction
     def _seal(self, items, castable) -> None:
         """Flat layout of a bucket: [ castable parameters | the rest ].  The castable masters are re-homed into one
-        flat fp32 buffer (``p.data`` becomes a view), so master -> working copy is ONE cast kernel."""
+        flat fp32 buffer (``p.data`` becomes a view), so master -> working copy is ONE cast kernel.
+        Every tensor starts at a multiple of ALIGN elements (16 B in the 2-byte working copy, 32 B in fp32): a bias of one
+        element (out_CFM / out_SAM) would otherwise leave every later weight, gradient and AdamW-state slice at an odd
+        byte phase, where 16-byte vector accesses are split.  The padding is zero in every buffer, so AdamW on it is a no-op."""
         dev = items[0][1].device
         work = [(n, p) for n, p in items if id(p) in castable]
         rest = [(n, p) for n, p in items if id(p) not in castable]
-        n_work, n_rest = sum(p.numel() for _, p in work), sum(p.numel() for _, p in rest)
+        pad_to = lambda n: -(-n // ALIGN) * ALIGN
+        n_work, n_rest = sum(pad_to(p.numel()) for _, p in work), sum(pad_to(p.numel()) for _, p in rest)
         flat = torch.zeros(n_work + n_rest, dtype=torch.float32, device=dev)          # fp32 gradients
-        mflat = torch.empty(n_work + n_rest, dtype=torch.float32, device=dev)            # fp32 masters of the whole bucket (flat: one AdamW launch per run)
-        wflat = torch.empty(n_work, dtype=self.working_dtype, device=dev) if n_work else None
-        masters, leaves, gviews, nhwc = [], [], [], []
+        mflat = torch.zeros(n_work + n_rest, dtype=torch.float32, device=dev)            # fp32 masters of the whole bucket (flat: one AdamW launch per run)
+        wflat = torch.zeros(n_work, dtype=self.working_dtype, device=dev) if n_work else None
+        masters, leaves, gviews, nhwc, offsets, modules = [], [], [], [], [], []
         off = 0
         with torch.no_grad():
             for _, p in work + rest:
@@ -132,6 +138,7 @@ class GradReducer:
                     m = castable[id(p)][0]
                     cl = tuple(m.stride) != tuple(m.kernel_size)
                 nhwc.append(cl)
+                offsets.append(off)
                 view = (lambda t: t.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)) if cl \
                     else (lambda t: t.view_as(p))
                 gv = view(flat[off:off + n])
@@ -148,16 +155,20 @@ class GradReducer:
                     object.__setattr__(m, attr, leaf)
                     p.requires_grad_(False)      # the master no longer takes part in autograd
                     leaves.append(leaf)
+                    modules.append((m, attr))
                 else:
                     mv = mflat[off:off + n].view_as(p)   # re-homed as well: the flat optimizer updates the bucket in place
                     mv.copy_(p.data)
                     p.data = mv
                     leaves.append(p)
-                off += n
+                    modules.append(None)
+                off += pad_to(n)
         self.buckets.append({"flat": flat, "mflat": mflat, "wflat": wflat, "n_work": n_work, "k_work": len(work),
-                             "masters": masters, "leaves": leaves, "gviews": gviews, "nhwc": nhwc,
+                             "masters": masters, "leaves": leaves, "gviews": gviews, "nhwc": nhwc, "offsets": offsets,
                              "names": [n_ for n_, _ in work + rest], "sizes": [p_.numel() for _, p_ in work + rest],
-                             "pending": len(items), "n": len(items), "done": False})
+                             "padded": [pad_to(p_.numel()) for _, p_ in work + rest], "shapes": [tuple(p_.shape) for _, p_ in work + rest],
+                             "modules": modules, "missing": (), "pads": {},
+                             "pending": len(items), "n": len(items), "done": False, "ready": False, "index": len(self.buckets)})
 
     # ------------------------------------------------------------------ per step
     @torch.no_grad()
@@ -167,21 +178,57 @@ class GradReducer:
             if b["wflat"] is not None:
                 b["wflat"].copy_(b["mflat"][:b["n_work"]])
 
+    def _install_load_hooks(self) -> None:
+        """``load_state_dict`` copies into the fp32 masters only; the modules compute with the working copies.  Every module
+        that owns a working copy refreshes it right after its own parameters were loaded (whichever (sub)module the caller
+        loaded through: runner.load_pretrained loads ``hitnet.backbone`` and ``encoder2`` directly)."""
+        def hook(module, _incompatible):
+            with torch.no_grad():
+                for attr, src in (("_w", module.weight), ("_b", module.bias)):
+                    leaf = getattr(module, attr, None)
+                    if leaf is not None and src is not None:
+                        leaf.copy_(src)
+        seen = set()
+        for b in self.buckets:
+            for ma in b["modules"]:
+                if ma is not None and id(ma[0]) not in seen:
+                    seen.add(id(ma[0]))
+                    ma[0].register_load_state_dict_post_hook(hook)
+
     def zero_grad(self) -> None:
         """Replaces optimizer.zero_grad(): leaves get .grad = None so autograd hands gradients over without an
         accumulate kernel; nothing is memset (the flat buckets are fully overwritten by _gather)."""
+        self._next = 0
         for b in self.buckets:
-            b["pending"], b["done"] = b["n"], False
+            b["pending"], b["done"], b["ready"] = b["n"], False, False
             for leaf in b["leaves"]:
                 leaf.grad = None
 
     def _make_hook(self, bucket):
         def hook(_leaf):
             bucket["pending"] -= 1
-            if bucket["pending"] == 0 and self.overlap:
-                self._gather(bucket)
-                self._launch(bucket)
+            if bucket["pending"] == 0:
+                bucket["ready"] = True
+                if self.overlap:
+                    self._advance()
         return hook
+
+    def _advance(self) -> None:
+        """Collectives are issued in BUCKET ORDER on every rank: bucket i goes out only once buckets < i have.  A bucket whose
+        last gradient never arrives on some rank (a parameter unused in that step) is left to finish(), which continues in the
+        same order, so the sequence of all-reduce sizes is identical on all ranks whatever the hook timing was."""
+        while self._next < len(self.buckets) and self.buckets[self._next]["ready"]:
+            b = self.buckets[self._next]
+            self._gather(b)
+            self._launch(b)
+            self._next += 1
+
+    def _pad(self, bucket, n: int, dtype):
+        key = (n, dtype)
+        z = bucket["pads"].get(key)
+        if z is None:
+            z = bucket["pads"][key] = torch.zeros(n, dtype=dtype, device=bucket["flat"].device)
+        return z
 
     @torch.no_grad()
     def _gather(self, bucket) -> None:
@@ -189,26 +236,38 @@ class GradReducer:
         low-precision segment) instead of a copy kernel per parameter; then restore the master .grad views."""
         flat, k, nw = bucket["flat"], bucket["k_work"], bucket["n_work"]
         leaves, gviews, nhwc = bucket["leaves"], bucket["gviews"], bucket["nhwc"]
+        sizes, padded = bucket["sizes"], bucket["padded"]
 
         def flat1d(g, cl):   # the gradient in the bucket's storage order (a view when its strides already match)
             return g.permute(0, 2, 3, 1).reshape(-1) if cl else g.reshape(-1)
+
+        missing = []
 
         def seg(lo, hi, out):
             if lo == hi:
                 return
             gs = [l.grad for l in leaves[lo:hi]]
-            if any(g is None for g in gs):   # a parameter unused this step: fall back to per-tensor copies
-                for g, gv in zip(gs, gviews[lo:hi]):
-                    gv.zero_() if g is None else gv.copy_(g)
+            if any(g is None for g in gs):   # a parameter unused this step: per-tensor copies; FlatAdamW skips its slot like torch.optim.AdamW skips grad None
+                for i, (g, gv) in enumerate(zip(gs, gviews[lo:hi])):
+                    if g is None:
+                        gv.zero_()
+                        missing.append(lo + i)
+                    else:
+                        gv.copy_(g)
                 return
-            parts = [flat1d(g, c) for g, c in zip(gs, nhwc[lo:hi])]
-            if gs[0].dtype == out.dtype:
+            parts = []
+            for i, (g, c) in enumerate(zip(gs, nhwc[lo:hi])):
+                parts.append(flat1d(g, c))
+                if padded[lo + i] != sizes[lo + i]:
+                    parts.append(self._pad(bucket, padded[lo + i] - sizes[lo + i], g.dtype))
+            if gs[0].dtype == out.dtype and all(g.dtype == out.dtype for g in gs):
                 torch.cat(parts, out=out)
             else:
                 out.copy_(torch.cat(parts))
 
         seg(0, k, flat[:nw])
         seg(k, len(leaves), flat[nw:])
+        bucket["missing"] = tuple(missing)
         for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
             leaf.grad = None            # free the per-leaf gradient
             p.grad = gv
@@ -234,11 +293,11 @@ class GradReducer:
         self._works.append(w)
 
     def finish(self) -> None:
-        """Call after backward(): gathers/launches whatever the hooks did not, then fences the compute stream."""
-        for b in self.buckets:
-            if not b["done"]:
-                self._gather(b)
-                self._launch(b)
+        """Call after backward(): gathers/launches whatever the hooks did not (in bucket order), then fences the compute stream."""
+        for b in self.buckets[self._next:]:
+            self._gather(b)
+            self._launch(b)
+        self._next = len(self.buckets)
         for w in self._works:
             w.wait()
         self._works.clear()

@@ -735,7 +735,9 @@ class cod(nn.Module):
 
     Extra keyword arguments (ignored by the reference, cod.py:38-46) are accepted and ignored.
     ``compute_dtype``: torch.float32 = exact-fp32 kernels (parity mode); torch.bfloat16 = bf16 MFMA
-    kernels + library GEMM/conv under bf16 autocast with fp32 master weights (throughput mode)."""
+    kernels + library GEMM/conv under bf16 autocast with fp32 master weights (throughput mode); torch.float16 = the same
+    with IEEE half (fp16 MFMA) - the reference's own AMP recipe (AmpOptimWrapper, config/sod.yml:57): pair it with
+    ``runner.LossScaler`` + ``runner.FlatAdamW(scaler=...)``."""
 
     def __init__(self, win_size=None, filter_ratio=None, using_depth=None, using_sam=None, finetune=None,
                  binary_thresh=None, pretrain_sam=None, head=None, img_size: int = 384,
@@ -760,8 +762,8 @@ class cod(nn.Module):
 
     def _run(self, input, depth, x_hp=None, lowres=False):
         self._draw_drop_path(input.shape[0])
-        if self.compute_dtype == torch.bfloat16:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+        if self.compute_dtype in (torch.bfloat16, torch.float16):
+            with torch.autocast("cuda", dtype=self.compute_dtype):
                 return self.hitnet(input, depth, x_hp, lowres)
         return self.hitnet(input, depth, x_hp, lowres)
 

@@ -1,4 +1,4 @@
-"""Dense 3x3 convolution (stride 1, padding 1) on NHWC bf16 maps with 24..96 channels over the C ABI (csrc/conv3x3.hip):
+"""Dense 3x3 convolution (stride 1, padding 1) on NHWC bf16 / fp16 maps with 24..96 channels over the C ABI (csrc/conv3x3.hip):
 the conv+ReLU pairs of the prompt decoders (twig/model/cod.py:1216-1226) and the CAB bodies (cod.py:441-446).
 Z independent convolutions run in one launch."""
 from __future__ import annotations
@@ -14,7 +14,7 @@ from . import _native
 
 
 def supported(x: torch.Tensor, Ci: int, Co: int, H: int, W: int) -> bool:
-    return bool(x.is_cuda and x.dtype == torch.bfloat16 and L.load().dgtd_conv3x3_supported(Ci, Co, H, W))
+    return bool(x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and L.load().dgtd_conv3x3_supported(Ci, Co, H, W))
 
 
 class _Conv3x3Fn(Function):
@@ -30,7 +30,7 @@ class _Conv3x3Fn(Function):
         bc = b.contiguous() if b is not None else None
         flops = 2.0 * Z * B * H * W * 9 * Ci * Co
         L.call("dgtd_conv3x3_fwd", L.ptr(x), None, L.ptr(w), L.ptr(bc), L.ptr(y), Z, B, H, W, Ci, Co, int(relu), int(shared),
-               L.stream_ptr(), algo=("hbm", 2 * (x.numel() + y.numel())), key=f"dgtd_conv3x3_fwd[Z={Z},{H}x{W},{Ci}->{Co}]")
+               L.dtype_code(x), L.stream_ptr(), algo=("hbm", 2 * (x.numel() + y.numel())), key=f"dgtd_conv3x3_fwd[Z={Z},{H}x{W},{Ci}->{Co}]")
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.meta = (relu, shared, b is not None, flops)
         return y
@@ -42,21 +42,21 @@ class _Conv3x3Fn(Function):
         relu, shared, has_b, _ = ctx.meta
         Z, Co, _, _, Ci = w.shape
         _, B, H, W, _ = x.shape
-        dy = dy.contiguous()
+        dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
         st = L.stream_ptr()
         dx = None
         if ctx.needs_input_grad[0]:
             wt = torch.empty(Z, Ci, 3, 3, Co, dtype=w.dtype, device=w.device)
             L.call("dgtd_conv3x3_flip", L.ptr(w), L.ptr(wt), Z, Co, Ci, st)
             dx = torch.empty(Z, B, H, W, Ci, dtype=x.dtype, device=x.device)
-            L.call("dgtd_conv3x3_fwd", L.ptr(dy), L.ptr(y), L.ptr(wt), None, L.ptr(dx), Z, B, H, W, Co, Ci, 0, 0, st,
+            L.call("dgtd_conv3x3_fwd", L.ptr(dy), L.ptr(y), L.ptr(wt), None, L.ptr(dx), Z, B, H, W, Co, Ci, 0, 0, L.dtype_code(dy), st,
                    algo=("hbm", 2 * (dx.numel() + (2 if relu else 1) * dy.numel())), key=f"dgtd_conv3x3_bwd_x[Z={Z},{H}x{W},{Co}->{Ci}]")
             if shared:
                 dx = dx.sum(0, keepdim=True)
         dw = torch.empty_like(w)
         db = torch.empty(Z, Co, dtype=w.dtype, device=w.device) if has_b else None
         ws = torch.empty(L.load().dgtd_conv3x3_wgrad_workspace(Z, B, H, W, Ci, Co), dtype=torch.uint8, device=x.device)
-        L.call("dgtd_conv3x3_wgrad", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(dw), L.ptr(db), L.ptr(ws), Z, B, H, W, Ci, Co, int(shared), st,
+        L.call("dgtd_conv3x3_wgrad", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(dw), L.ptr(db), L.ptr(ws), Z, B, H, W, Ci, Co, int(shared), L.dtype_code(x), st,
                algo=("hbm", 2 * ((1 if shared else Z) * B * H * W * Ci + (2 if relu else 1) * dy.numel())),
                key=f"dgtd_conv3x3_wgrad[Z={Z},{H}x{W},{Ci}->{Co}]")
         return dx, dw, db, None

@@ -10,6 +10,7 @@ from .. import _lib as L
 from . import _native
 
 _WS = {}
+_CODES = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}   # compute dtypes of the C++ Linear nodes
 SPLITK_WGRAD = os.environ.get("DGTD_SPLITK_WGRAD", "1") != "0"   # A/B switch for tools/ and bench runs
 
 
@@ -142,9 +143,9 @@ def linear(x, w, b=None):
     nat = _native.ops()
     if nat is not None and x.is_cuda and SPLITK_WGRAD:
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        if dt in (torch.float32, torch.bfloat16):
+        if dt in _CODES:
             with torch.autocast("cuda", enabled=False):
-                return nat.linear(x, w, b, 1 if dt == torch.bfloat16 else 0)
+                return nat.linear(x, w, b, _CODES[dt])
     return _LinearFn.apply(x, w, b)
 
 
@@ -154,9 +155,9 @@ def _native_dt(x):
     if nat is None or not x.is_cuda or not SPLITK_WGRAD:
         return None, None
     dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-    if dt not in (torch.float32, torch.bfloat16):
+    if dt not in _CODES:
         return None, None
-    return nat, (1 if dt == torch.bfloat16 else 0)
+    return nat, _CODES[dt]
 
 
 def linear_gelu(x, w, b):

@@ -1,5 +1,6 @@
 """Minimal pieces of the training loop the reference delegates to nest/mmengine."""
-from .optim import FlatAdamW, build_optimizer, lr_mult_for  # noqa: F401
-from .data import SyntheticRGBD, device_preprocess, device_sample  # noqa: F401
-from .checkpoint import load_checkpoint, load_pretrained, save_checkpoint  # noqa: F401
+from .optim import FlatAdamW, LossScaler, build_optimizer, lr_mult_for  # noqa: F401
+from .data import DefaultSampler, SyntheticRGBD, batches, device_preprocess, device_sample
+from . import metrics  # noqa: F401  # noqa: F401
+from .checkpoint import load_checkpoint, load_checkpoint_file, load_pretrained, save_checkpoint  # noqa: F401
 from .config import CosineByEpoch, Runner, build_model, build_optim, load_config  # noqa: F401

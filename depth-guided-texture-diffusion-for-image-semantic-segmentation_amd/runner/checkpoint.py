@@ -6,7 +6,10 @@
 * ``load_checkpoint``  = our_init.before_val: mmengine layout, weights under ``['state_dict']`` (cod.py:299).
 * ``save_checkpoint``  writes that layout (``state_dict`` / ``optimizer`` / ``param_schedulers`` / ``meta``), fp32 masters only:
   working copies and DropPath plans are not part of the state_dict.
-Parameter names and shapes are identical to the reference's (879 keys), so files move in both directions unchanged."""
+Parameter names and shapes are identical to the reference's (879 keys), so model weights move in both directions unchanged; the
+``optimizer`` entry has torch.optim.AdamW's state_dict layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``) whichever of
+the two optimizers wrote it.  A model that already has a ``dist.GradReducer`` keeps computing with working copies: the reducer's
+load hooks refresh them whenever a (sub)module's state is loaded."""
 from __future__ import annotations
 
 import os
@@ -31,8 +34,14 @@ def load_pretrained(model: torch.nn.Module, pvt_path: Optional[str] = "pretrain/
     return report
 
 
-def load_checkpoint(model: torch.nn.Module, path: str, map_location="cpu", strict: bool = False):
-    ckpt = _unwrap(torch.load(path, map_location=map_location, weights_only=False), "model")
+def load_checkpoint_file(path: str, map_location="cpu", weights_only: bool = True):
+    """torch.load restricted to tensors and plain containers by default; ``weights_only=False`` is the explicit opt-out for files
+    from a trusted source that pickle other objects (mmengine checkpoints carry such objects under ``meta`` / ``message_hub``)."""
+    return torch.load(path, map_location=map_location, weights_only=weights_only)
+
+
+def load_checkpoint(model: torch.nn.Module, path: str, map_location="cpu", strict: bool = False, weights_only: bool = True):
+    ckpt = _unwrap(load_checkpoint_file(path, map_location, weights_only), "model")
     return model.load_state_dict(_unwrap(ckpt, "state_dict"), strict=strict)
 
 

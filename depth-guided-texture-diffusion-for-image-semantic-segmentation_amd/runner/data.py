@@ -7,9 +7,74 @@ import torch
 import torch.nn.functional as F
 
 
+class DefaultSampler:
+    """mmengine.dataset.DefaultSampler as both configs select it (config/sod.yml:24-26, :35-37): a permutation seeded with
+    ``seed + epoch`` (identical on every rank) when ``shuffle``, padded by repetition to a multiple of the world size
+    (``round_up``), of which rank r takes ``indices[r::world]``."""
+
+    def __init__(self, length: int, shuffle: bool = True, seed: int = 0, rank: int = 0, world: int = 1, round_up: bool = True):
+        self.length, self.shuffle, self.seed, self.rank, self.world, self.round_up = int(length), shuffle, int(seed), rank, world, round_up
+        self.epoch = 0
+        if round_up:
+            self.num_samples = -(-self.length // world)
+            self.total_size = self.num_samples * world
+        else:
+            self.num_samples = -(-(self.length - rank) // world)
+            self.total_size = self.length
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            indices = torch.randperm(self.length, generator=g).tolist()
+        else:
+            indices = list(range(self.length))
+        if self.round_up:
+            indices = (indices * int(self.total_size / len(indices) + 1))[:self.total_size]
+        return iter(indices[self.rank:self.total_size:self.world])
+
+
+def batches(dataset, sampler, batch_size: int, device=None, drop_last: bool = False):
+    """Batches in the form mmengine's pseudo_collate hands to ``cod.forward``: a dict of per-key LISTS of per-sample values."""
+    cur = []
+    for idx in sampler:
+        cur.append(dataset[idx])
+        if len(cur) == batch_size:
+            yield _collate(cur, device)
+            cur = []
+    if cur and not drop_last:
+        yield _collate(cur, device)
+
+
+def _collate(items, device):
+    out = {}
+    for k in items[0]:
+        vals = [it[k] for it in items]
+        out[k] = [v.to(device, non_blocking=True) for v in vals] if (device is not None and torch.is_tensor(vals[0])) else vals
+    return out
+
+
 class SyntheticRGBD:
-    def __init__(self, size: int, batch: int, rank: int = 0, device="cuda", seed: int = 1234):
-        self.size, self.batch, self.rank, self.device, self.seed = size, batch, rank, device, seed
+    def __init__(self, size: int, batch: int, rank: int = 0, device="cuda", seed: int = 1234, length: int = 1 << 20):
+        self.size, self.batch, self.rank, self.device, self.seed, self.length = size, batch, rank, device, seed, length
+
+    def __len__(self) -> int:
+        return self.length
+
+    def __getitem__(self, index: int):
+        """Dataset view (twig/dataset/sod_train.py:55-83 contract): the sample depends on the index only; which rank sees it is
+        the sampler's business."""
+        rank, self.rank = self.rank, 0
+        try:
+            return self.sample(index)
+        finally:
+            self.rank = rank
 
     def sample(self, index: int):
         g = torch.Generator(device="cpu").manual_seed(self.seed + self.rank * 10 ** 6 + index)

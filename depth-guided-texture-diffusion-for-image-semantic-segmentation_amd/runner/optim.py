@@ -43,37 +43,85 @@ def build_optimizer(model: torch.nn.Module, lr: float = 5e-4, weight_decay: floa
 
 
 
+class LossScaler:
+    """Dynamic loss scaling with torch.amp.GradScaler's rule (the reference's AmpOptimWrapper, config/sod.yml:57): the loss is
+    multiplied by ``scale``; a step whose gradients hold an inf / NaN is skipped and halves the scale, ``growth_interval`` clean
+    steps in a row double it.  All state lives on the device (``state`` = [scale, growth_tracker, 1/scale, found_inf, optimizer
+    steps actually taken]) and is updated by ``dgtd_loss_scale_update``: no host synchronisation per step."""
+
+    def __init__(self, device, init_scale: float = 2.0 ** 16, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, int(growth_interval)
+        self.state = torch.tensor([init_scale, 0.0, 1.0 / init_scale, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self.state[0]
+
+    def get_scale(self) -> float:
+        return float(self.state[0].item())
+
+    def state_dict(self) -> dict:
+        st = self.state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[1]), "steps_taken": int(st[4])}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.state.copy_(torch.tensor([sd["scale"], float(sd["_growth_tracker"]), 1.0 / sd["scale"], 0.0, float(sd.get("steps_taken", 0))]))
+
+
 class FlatAdamW:
     """AdamW over the flat buckets of a ``dist.GradReducer``: one ``dgtd_adamw_flat`` launch per run of equal learning rate per
-    bucket (≈ 20 launches for 114 M parameters) that also rewrites the bf16 working copies, instead of torch's multi-tensor AdamW
+    bucket (≈ 20 launches for 114 M parameters) that also rewrites the 16-bit working copies, instead of torch's multi-tensor AdamW
     plus one cast per bucket.  Same update rule and defaults as ``torch.optim.AdamW``; ``param_groups`` carries one entry per
-    distinct lr multiplier so the reference's epoch-wise cosine schedule (config/sod.yml:78-83) drives it unchanged."""
+    distinct lr multiplier so the reference's epoch-wise cosine schedule (config/sod.yml:78-83) drives it unchanged.
+    ``scaler``: a ``LossScaler`` (fp16 mode): the gradients are checked for inf / NaN (one pass per bucket), un-scaled inside
+    the AdamW launch, and an overflowed step is skipped on the device.
+    ``state_dict()`` has torch.optim.AdamW's layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in the parameters'
+    logical shapes, ``param_groups`` with parameter indices, plus ``param_names``), whatever the bucket size was."""
 
     def __init__(self, reducer, lr: float = 5e-4, weight_decay: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8,
-                 custom_keys: Optional[Dict[str, float]] = None):
+                 custom_keys: Optional[Dict[str, float]] = None, scaler: Optional[LossScaler] = None):
         from .. import _lib as L
         self._L = L
-        self.reducer = reducer
+        self.reducer, self.scaler = reducer, scaler
         custom_keys = SOD_CUSTOM_KEYS if custom_keys is None else custom_keys
-        self.betas, self.eps, self.weight_decay, self.steps = betas, eps, weight_decay, 0
+        self.betas, self.eps, self.weight_decay, self._steps = betas, eps, weight_decay, 0
         mults = sorted({lr_mult_for(n, custom_keys) for b in reducer.buckets for n in b["names"]}, reverse=True)
         self.param_groups = [{"lr": lr * m, "initial_lr": lr * m, "mult": m, "weight_decay": weight_decay} for m in mults]
         gidx = {m: i for i, m in enumerate(mults)}
-        self.runs, self.state = [], []
+        self.slots, self.runs, self.state = [], [], []
         for b in reducer.buckets:
             if not b["mflat"].is_cuda:
                 raise RuntimeError("FlatAdamW runs on the HIP device; use build_optimizer() (torch.optim.AdamW) on CPU")
-            runs, off = [], 0
-            for name, n in zip(b["names"], b["sizes"]):
-                g = gidx[lr_mult_for(name, custom_keys)]
-                # a run = contiguous elements with one lr that lie on one side of the working-copy boundary
-                if runs and runs[-1][2] == g and not (off == b["n_work"]):
-                    runs[-1][1] = off + n
-                else:
-                    runs.append([off, off + n, g])
-                off += n
-            self.runs.append(runs)
+            # slot = (offset, padded length, group); the alignment padding after a tensor travels with it (zeros: a no-op update)
+            slots = [(off, n, gidx[lr_mult_for(name, custom_keys)]) for name, off, n in zip(b["names"], b["offsets"], b["padded"])]
+            self.slots.append(slots)
+            self.runs.append(self._merge(slots, b["n_work"], ()))
             self.state.append({"exp_avg": torch.zeros_like(b["mflat"]), "exp_avg_sq": torch.zeros_like(b["mflat"])})
+        wd = reducer.working_dtype
+        self._w_dt = L.F16 if wd == torch.float16 else L.BF16
+
+    @property
+    def steps(self) -> int:
+        """Optimizer steps actually taken (fp16 mode: read from the scaler's device state - steps it skipped do not count)."""
+        return int(self.scaler.state[4].item()) if self.scaler is not None else self._steps
+
+    @staticmethod
+    def _merge(slots, n_work, missing):
+        """Runs = maximal contiguous stretches with one lr on one side of the working-copy boundary, skipping ``missing`` slots."""
+        runs, prev_end = [], None
+        for i, (off, n, g) in enumerate(slots):
+            if i in missing:
+                prev_end = None
+                continue
+            if runs and prev_end == off and runs[-1][2] == g and off != n_work:
+                runs[-1][1] = off + n
+            else:
+                runs.append([off, off + n, g])
+            prev_end = off + n
+        return runs
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.reducer.zero_grad()
@@ -81,25 +129,75 @@ class FlatAdamW:
     @torch.no_grad()
     def step(self) -> None:
         L = self._L
-        self.steps += 1
+        self._steps += 1
         b1, b2 = self.betas
-        bc1, bc2 = 1.0 - b1 ** self.steps, 1.0 - b2 ** self.steps
+        bc1, bc2 = 1.0 - b1 ** self._steps, 1.0 - b2 ** self._steps
         st = L.stream_ptr()
-        for b, runs, state in zip(self.reducer.buckets, self.runs, self.state):
+        amp = None
+        if self.scaler is not None:
+            amp = self.scaler.state.data_ptr()
+            for b in self.reducer.buckets:          # GradScaler.unscale_'s found_inf over every (already all-reduced) gradient
+                L.call("dgtd_found_inf", b["flat"].data_ptr(), b["flat"].numel(), amp + 12, st)
+        for b, slots, runs, state in zip(self.reducer.buckets, self.slots, self.runs, self.state):
             p, g, m, v, w, nw = b["mflat"], b["flat"], state["exp_avg"], state["exp_avg_sq"], b["wflat"], b["n_work"]
+            if b["missing"]:                        # parameters without a gradient this step are skipped, like torch.optim.AdamW does
+                runs = self._merge(slots, nw, set(b["missing"]))
             for lo, hi, gi in runs:
                 wp = (w.data_ptr() + 2 * lo) if (w is not None and hi <= nw) else None
-                L.call("dgtd_adamw_flat", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, wp,
-                       hi - lo, float(self.param_groups[gi]["lr"]), b1, b2, self.eps, float(self.param_groups[gi]["weight_decay"]), bc1, bc2, st)
+                L.call("dgtd_adamw_flat_amp", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, wp,
+                       self._w_dt, hi - lo, float(self.param_groups[gi]["lr"]), b1, b2, self.eps,
+                       float(self.param_groups[gi]["weight_decay"]), bc1, bc2, amp, st)
+        if self.scaler is not None:
+            L.call("dgtd_loss_scale_update", self.scaler.state.data_ptr(), float(self.scaler.growth_factor),
+                   float(self.scaler.backoff_factor), int(self.scaler.growth_interval), st)
+
+    # ------------------------------------------------------------------ torch.optim.AdamW-compatible state
+    def _logical(self, b, i, flat):
+        off, n, shape = b["offsets"][i], b["sizes"][i], b["shapes"][i]
+        t = flat[off:off + n]
+        if b["nhwc"][i]:
+            return t.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2)
+        return t.view(shape)
 
     def state_dict(self) -> dict:
-        return {"steps": self.steps, "param_groups": [dict(g) for g in self.param_groups],
-                "exp_avg": [s["exp_avg"].clone() for s in self.state], "exp_avg_sq": [s["exp_avg_sq"].clone() for s in self.state]}
+        steps = self.steps
+        names, state, members = [], {}, [[] for _ in self.param_groups]
+        for b, slots, st in zip(self.reducer.buckets, self.slots, self.state):
+            for i, name in enumerate(b["names"]):
+                idx = len(names)
+                names.append(name)
+                members[slots[i][2]].append(idx)
+                state[idx] = {"step": torch.tensor(float(steps)),
+                              "exp_avg": self._logical(b, i, st["exp_avg"]).detach().cpu().contiguous(),
+                              "exp_avg_sq": self._logical(b, i, st["exp_avg_sq"]).detach().cpu().contiguous()}
+        groups = [{"lr": g["lr"], "initial_lr": g["initial_lr"], "betas": tuple(self.betas), "eps": self.eps,
+                   "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False, "params": members[i]}
+                  for i, g in enumerate(self.param_groups)]
+        out = {"state": state, "param_groups": groups, "param_names": names}
+        if self.scaler is not None:
+            out["loss_scaler"] = self.scaler.state_dict()
+        return out
 
+    @torch.no_grad()
     def load_state_dict(self, sd: dict) -> None:
-        self.steps = int(sd["steps"])
-        for g, src in zip(self.param_groups, sd["param_groups"]):
-            g.update(src)
-        for s, a, b in zip(self.state, sd["exp_avg"], sd["exp_avg_sq"]):
-            s["exp_avg"].copy_(a)
-            s["exp_avg_sq"].copy_(b)
+        names = sd.get("param_names")
+        index = {n: i for i, n in enumerate(names)} if names is not None else None
+        steps, k = None, 0
+        for b, st in zip(self.reducer.buckets, self.state):
+            for i, name in enumerate(b["names"]):
+                idx = index[name] if index is not None else k
+                k += 1
+                src = sd["state"][idx]
+                if tuple(src["exp_avg"].shape) != b["shapes"][i]:
+                    raise ValueError(f"optimizer state of {name}: shape {tuple(src['exp_avg'].shape)} != parameter shape {b['shapes'][i]}")
+                self._logical(b, i, st["exp_avg"]).copy_(src["exp_avg"])
+                self._logical(b, i, st["exp_avg_sq"]).copy_(src["exp_avg_sq"])
+                steps = int(float(src["step"])) if steps is None else steps
+        self._steps = steps or 0
+        if self.scaler is not None:
+            self.scaler.state[4] = float(self._steps)
+        by_mult = sorted(sd["param_groups"], key=lambda g: -g["initial_lr"])
+        for g, src in zip(self.param_groups, by_mult):
+            g["lr"], g["initial_lr"], g["weight_decay"] = src["lr"], src["initial_lr"], src["weight_decay"]
+        if self.scaler is not None and "loss_scaler" in sd:
+            self.scaler.load_state_dict(sd["loss_scaler"])

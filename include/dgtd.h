@@ -15,8 +15,10 @@
  *     autograd's device thread.
  *
  * dtype: DGTD_F32 = exact-fp32 kernels (parity mode, fp32 MFMA); DGTD_BF16 = bf16 I/O with
- * fp32 accumulation (throughput mode, bf16 MFMA).  Statistics (lse, mean, rstd) and all
- * parameter gradients are always fp32.
+ * fp32 accumulation (throughput mode, bf16 MFMA); DGTD_F16 = IEEE half I/O with fp32 accumulation
+ * (fp16 MFMA) - the reference's own AMP recipe, AmpOptimWrapper = fp16 autocast + fp32 masters +
+ * dynamic loss scaling (config/sod.yml:57, config/cod.yml:58).  Wherever DGTD_BF16 is accepted
+ * DGTD_F16 is too.  Statistics (lse, mean, rstd) are always fp32.
  */
 #ifndef DGTD_H
 #define DGTD_H
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-typedef enum { DGTD_F32 = 0, DGTD_BF16 = 1, DGTD_F64 = 2 /* ms_deform_attn only */ } dgtd_dtype;
+typedef enum { DGTD_F32 = 0, DGTD_BF16 = 1, DGTD_F64 = 2 /* ms_deform_attn only */, DGTD_F16 = 3 } dgtd_dtype;
 typedef void* dgtd_stream; /* hipStream_t */
 
 int dgtd_version(void);
@@ -175,19 +177,19 @@ int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, i
  * replaces the conv3x3(24->24)+ReLU pairs of the 16 prompt decoders (ShapePropDecoder, twig/model/cod.py:1216-1226, called at
  * cod.py:1316-1323) and the conv3x3 C->C bodies of the Hitnet CABs (cod.py:441-446).  Z independent convolutions per launch:
  * x [Z,B,H,W,Ci] (or [B,H,W,Ci] shared by all Z when shared_x != 0), w [Z,Co,3,3,Ci] (Conv2d weight in O,H,W,I order),
- * bias [Z,Co] or NULL, y [Z,B,H,W,Co]; all bf16, fp32 accumulation.  Ci, Co in {24, 32, 64, 96}; W a multiple of 16.
+ * bias [Z,Co] or NULL, y [Z,B,H,W,Co]; all of dtype dt (DGTD_BF16 or DGTD_F16), fp32 accumulation.  Ci, Co in {24, 32, 64, 96}; W a multiple of 16.
  * mask (NULL or the shape of x): x is taken as zero where mask <= 0 - the ReLU backward fused into the tile load.
  * Backward w.r.t. x = dgtd_conv3x3_fwd on dy with the kernel from dgtd_conv3x3_flip (Ci and Co swapped, mask = forward output). */
 int dgtd_conv3x3_supported(int Ci, int Co, int H, int W);
 int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
-                     int Ci, int Co, int relu, int shared_x, dgtd_stream s);
-/* wt [Z,Ci,3,3,Co] = w [Z,Co,3,3,Ci] transposed, taps flipped.                                                                  */
+                     int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s);
+/* wt [Z,Ci,3,3,Co] = w [Z,Co,3,3,Ci] transposed, taps flipped (any 2-byte dtype).                                                                */
 int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s);
-/* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) bf16, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).
+/* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) of dtype dt, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).
  * workspace: dgtd_conv3x3_wgrad_workspace(...) bytes of per-workgroup partial sums, reduced in a fixed order.                   */
 int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co);
 int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
-                       int H, int W, int Ci, int Co, int shared_x, dgtd_stream s);
+                       int H, int W, int Ci, int Co, int shared_x, dgtd_dtype dt, dgtd_stream s);
 
 /* ---- AdamW over one contiguous run of a flat fp32 parameter bucket (+ the bf16 working copy in the same pass) ----
  * replaces torch.optim.AdamW(fused) per the reference's optim_wrapper (config/sod.yml:56-76: AdamW, weight_decay 0.1, per-prefix
@@ -195,6 +197,21 @@ int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw
  * p *= 1-lr*wd; m += (1-b1)(g-m); v = b2 v + (1-b2) g*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); w = bf16(p).               */
 int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float bias_correction1, float bias_correction2, dgtd_stream s);
+
+/* The same with the working copy in w_dt (DGTD_BF16 or DGTD_F16) and the reference's AMP recipe (AmpOptimWrapper = GradScaler,
+ * config/sod.yml:57) folded in.  amp_state (device, fp32 [5] = { scale, growth_tracker, 1/scale, found_inf, steps taken }, or NULL):
+ * gradients are multiplied by 1/scale, the whole launch is a no-op when found_inf != 0 (GradScaler.unscale_ + the skipped step of
+ * an overflowed iteration) and the bias corrections are 1 - beta^(steps taken + 1) computed on the device (skipped steps do not
+ * count; bias_correction1/2 are ignored).                                                                                        */
+int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                        const float* amp_state, dgtd_stream s);
+/* found[0] = 1 when g[0,n) (fp32, the still scaled gradients) holds an inf or a NaN; untouched otherwise.                        */
+int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s);
+/* GradScaler.update() on the device: state fp32 [5] (layout above); found_inf != 0: scale *= backoff, tracker = 0; else steps += 1,
+ * tracker += 1 and every growth_interval clean steps scale *= growth (kept when the product overflows); found_inf is cleared.
+ * No host synchronisation anywhere in the scaled step.                                                      */
+int dgtd_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, dgtd_stream s);
 
 /* ---- Multi-scale deformable attention sampling: the reference's own native op (twig/ops) ------------------------
  * replaces MSDA.ms_deform_attn_forward / ms_deform_attn_backward (twig/ops/src/ms_deform_attn.h:20-60, bound at

@@ -114,3 +114,84 @@ def test_checkpoint_layouts_roundtrip(model, tmp_path):
     assert all(m.startswith(("convs.", "fusion_conv.")) for m in rep["convnext"].missing_keys)
     kk = "hitnet.backbone.prompt_encoder.encoder2.stages.2.26.pwconv1.weight"
     assert torch.equal(fresh.state_dict()[kk], net.state_dict()[kk])
+
+
+def test_default_sampler_partitions_a_seeded_permutation_rank_strided():
+    """mmengine DefaultSampler (config/sod.yml:24-26): every rank builds the SAME permutation from seed + epoch, pads it by
+    repetition to a multiple of the world size and takes indices[rank::world]."""
+    import dgtd
+    N, world = 10, 4
+    per_rank = []
+    for r in range(world):
+        s = dgtd.runner.DefaultSampler(N, shuffle=True, seed=7, rank=r, world=world)
+        s.set_epoch(3)
+        per_rank.append(list(s))
+        assert len(per_rank[-1]) == len(s) == 3
+    g = torch.Generator()
+    g.manual_seed(7 + 3)
+    perm = torch.randperm(N, generator=g).tolist()
+    padded = (perm * 2)[:12]
+    assert [padded[r::world] for r in range(world)] == per_rank
+    assert sorted(set(sum(per_rank, []))) == list(range(N))           # every sample is seen
+    s0 = dgtd.runner.DefaultSampler(N, shuffle=True, seed=7, rank=0, world=world)
+    s0.set_epoch(4)
+    assert list(s0) != per_rank[0]                                    # the permutation changes with the epoch
+    val = dgtd.runner.DefaultSampler(5, shuffle=False, rank=1, world=2)
+    assert list(val) == [1, 3, 0]                                     # sequential, round_up wraps to the start
+    ds = dgtd.runner.SyntheticRGBD(32, 2, device="cpu", length=5)
+    bs = list(dgtd.runner.batches(ds, val, 2, "cpu"))
+    assert [len(b["input"]) for b in bs] == [2, 1] and bs[0]["raw"][0].endswith("/1.png")
+    assert torch.equal(bs[0]["input"][1], ds[3]["input"])
+
+
+def test_metric_restatements_match_the_reference_goldens():
+    """runner.metrics.mean_iou_reference against values computed by the reference's own meanIntersectionOverUnion.mean_iou
+    (twig/metric/mIOU.py:32-58; oracle/make_golden_metrics.py)."""
+    import numpy as np
+    import dgtd
+    from oracle.make_golden_metrics import CASES, GOLDEN, case_inputs
+    g = np.load(GOLDEN)
+    for case in CASES:
+        pred, target = case_inputs(*case)
+        got = dgtd.runner.metrics.mean_iou_reference(pred, target)
+        assert abs(got - float(g[case[0]])) < 1e-6, case[0]
+    assert float(g["c1"]) == 1.0                                      # one output channel: identically 1 (SURVEY 0)
+    # binary 2-class mIoU: hand-checked 2x2 case: pred>0.5 = [[1,0],[1,1]], gt = [[1,0],[0,1]]
+    p = torch.tensor([[[[0.9, 0.1], [0.8, 0.7]]]])
+    t = torch.tensor([[[[1.0, 0.0], [0.0, 1.0]]]])
+    # class 0: TP 1, FP 0, FN 1 -> 1/2; class 1: TP 2, FP 1, FN 0 -> 2/3
+    assert abs(dgtd.runner.metrics.binary_miou(p, t) - (0.5 + 2 / 3) / 2) < 1e-9
+    ev = dgtd.runner.metrics.build_evaluators([{"type": "Emeasure"}, {"type": "MAE"}], log=lambda m: None)
+    assert [type(e).__name__ for e in ev] == ["MAE"]
+    ev[0].process(None, (p, t))
+    # uint8 quantisation + min-max normalisation: pred -> [229,25,204,178]/255 -> (x - 25/255)/(204/255)
+    q = torch.tensor([229., 25., 204., 178.])
+    want = ((q - 25) / 204 - torch.tensor([1., 0., 0., 1.])).abs().mean().item()
+    assert abs(ev[0].compute_metrics()["MAE"] - want) < 1e-6
+
+
+def test_live_reference_miou_when_available():
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present")
+    import dgtd
+    from oracle.make_golden_metrics import CASES, case_inputs, load_reference_metric
+    metric = load_reference_metric()
+    for case in CASES:
+        pred, target = case_inputs(*case)
+        assert abs(float(metric.mean_iou(pred.clone(), target.clone())) - dgtd.runner.metrics.mean_iou_reference(pred, target)) < 1e-6
+
+
+def test_cosine_schedule_resumes():
+    import dgtd
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    a = dgtd.runner.CosineByEpoch(opt, 10)
+    for _ in range(4):
+        a.step()
+    lr4 = opt.param_groups[0]["lr"]
+    opt2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    b = dgtd.runner.CosineByEpoch(opt2, 10)
+    b.load_state_dict(a.state_dict())
+    assert opt2.param_groups[0]["lr"] == lr4
+    a.step(); b.step()
+    assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
