@@ -41,6 +41,28 @@ def digest(t: torch.Tensor, nsamp: int = 4096) -> dict:
             "samples": f[::step].float().numpy()}
 
 
+GRAD_SAMPLES = 16
+
+
+def grad_samples(g: torch.Tensor) -> np.ndarray:
+    """GRAD_SAMPLES evenly strided elements of the gradient in logical (contiguous) element order, zero padded."""
+    f = g.detach().contiguous().flatten().float()
+    step = max(f.numel() // GRAD_SAMPLES, 1)
+    v = f[::step][:GRAD_SAMPLES].cpu().numpy()
+    return np.pad(v, (0, GRAD_SAMPLES - v.size))
+
+
+def sign_pattern(n: int, device="cpu") -> torch.Tensor:
+    """Deterministic +-1 pattern over n elements (integer hash of the element index; no RNG)."""
+    i = torch.arange(n, dtype=torch.int64, device=device)
+    return (1 - 2 * (((i * 2654435761) >> 15) & 1)).double()
+
+
+def grad_projection(g: torch.Tensor) -> float:
+    f = g.detach().contiguous().flatten().double()
+    return float((f * sign_pattern(f.numel(), f.device)).sum())
+
+
 # (name, dim, heads, sr, H=W, B) — the four PVT-b2 stage shapes (cod.py:1785-1786) at S=128 and stage 1 at S=512
 ATTN_CASES = [("attn_s1", 64, 1, 8, 32, 2), ("attn_s2", 128, 2, 4, 16, 2), ("attn_s3", 320, 5, 2, 8, 2),
               ("attn_s4", 512, 8, 1, 4, 2), ("attn_s1_512", 64, 1, 8, 128, 1)]
@@ -148,12 +170,18 @@ def gen_model(S: int, B: int, with_grads: bool) -> dict:
         loss = net(None, x, l, list(d), mode="loss")["loss"]
         out["train.loss"] = np.float64(loss.item())
         loss.backward()
-        names, norms = [], []
+        names, norms, samples, projs = [], [], [], []
         for k, p in net.named_parameters():
             names.append(k)
             norms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+            samples.append(np.zeros(GRAD_SAMPLES, np.float32) if p.grad is None else grad_samples(p.grad))
+            projs.append(0.0 if p.grad is None else grad_projection(p.grad))
         out["train.grad_names"] = np.array(names)
         out["train.grad_norms"] = np.array(norms, dtype=np.float64)
+        # element-level fingerprints (a transposed / permuted / sign-flipped gradient keeps its norm): strided samples in the logical
+        # (O,I,H,W) element order and the dot product with a fixed +-1 pattern
+        out["train.grad_samples"] = np.stack(samples)
+        out["train.grad_proj"] = np.array(projs, dtype=np.float64)
         bn = {k: v for k, v in net.state_dict().items() if "running_" in k}
         out["train.bn_names"] = np.array(list(bn))
         out["train.bn_values"] = np.concatenate([v.flatten().numpy() for v in bn.values()])

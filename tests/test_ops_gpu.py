@@ -22,6 +22,12 @@ def dgtd(request):
     m.ops._native.ENABLED = old
 
 
+# fp32 = exact kernels (parity mode); bf16 = throughput mode; fp16 = the reference's own AMP dtype (config/sod.yml:57), same kernels on the
+# f16 MFMA / conversions.  Tolerances below treat both 16-bit types alike (fp16 has 3 more mantissa bits than bf16).
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+HALVES = [torch.bfloat16, torch.float16]
+
+
 def _rand(*shape, seed=0, dtype=torch.float32, scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to("cuda").to(dtype)
@@ -29,7 +35,7 @@ def _rand(*shape, seed=0, dtype=torch.float32, scale=1.0):
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("C", [64, 128, 320, 512, 256, 1024])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_layernorm_fwd_bwd(dgtd, C, dtype):
     rows = 777  # ragged vs rows-per-block
     x = _rand(rows, C, seed=C, dtype=dtype)
@@ -69,7 +75,7 @@ ATTN_SHAPES = [(2, 4096, 64, 1), (2, 1024, 64, 2), (2, 256, 64, 5), (2, 64, 64, 
 
 
 @pytest.mark.parametrize("shape", ATTN_SHAPES, ids=[str(s) for s in ATTN_SHAPES])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_sra_attention_fwd_bwd(dgtd, shape, dtype):
     B, N, Nkv, heads = shape
     C = heads * 64
@@ -105,9 +111,10 @@ def test_attention_spiked_scores_online_softmax(dgtd):
     ref = _attn_ref(q, kv, heads, 0.125)
     out = dgtd.ops.sra_attention(q, kv, heads, 0.125)
     torch.testing.assert_close(out, ref, atol=2e-5, rtol=2e-5)
-    out16 = dgtd.ops.sra_attention(q.bfloat16(), kv.bfloat16(), heads, 0.125)
-    ref16 = _attn_ref(q.bfloat16().float(), kv.bfloat16().float(), heads, 0.125)
-    torch.testing.assert_close(out16.float(), ref16, atol=3e-2, rtol=3e-2)
+    for half in HALVES:
+        out16 = dgtd.ops.sra_attention(q.to(half), kv.to(half), heads, 0.125)
+        ref16 = _attn_ref(q.to(half).float(), kv.to(half).float(), heads, 0.125)
+        torch.testing.assert_close(out16.float(), ref16, atol=3e-2, rtol=3e-2)
 
 
 # ---------------------------------------------------------------------------------------------- texture diffuser
@@ -141,7 +148,7 @@ def test_diffuser_front_end_vs_oracle(dgtd, S):
 
 # ---------------------------------------------------------------------------------------------- fused epilogues
 @pytest.mark.parametrize("C", [64, 320, 1024, 2048])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("with_s,with_g", [(True, True), (True, False), (False, True)])
 def test_scale_residual_fwd_bwd(dgtd, C, dtype, with_s, with_g):
     B, N = 3, 173
@@ -166,7 +173,7 @@ def test_scale_residual_fwd_bwd(dgtd, C, dtype, with_s, with_g):
 
 
 @pytest.mark.parametrize("rows,K,N", [(1000, 64, 512), (77, 320, 1280), (4, 2048, 512)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_linear_with_colsum_bias_grad(dgtd, rows, K, N, dtype):
     x = _rand(2, rows, K, seed=1, dtype=dtype)
     w = _rand(N, K, seed=2, dtype=dtype, scale=K ** -0.5)
@@ -212,7 +219,7 @@ def test_seg_loss_vs_oracle(dgtd, S, hs, B):
 
 # ---------------------------------------------------------------------------------------------- Hitnet CAB glue
 @pytest.mark.parametrize("shape", [(2, 32, 16, 16), (3, 96, 20, 12), (2, 64, 128, 128)], ids=str)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("channels_last", [True, False])
 def test_prelu_shared_slope(dgtd, shape, dtype, channels_last):
     x = _rand(*shape, seed=5, dtype=dtype)
@@ -234,7 +241,7 @@ def test_prelu_shared_slope(dgtd, shape, dtype, channels_last):
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (3, 64, 12, 20), (2, 96, 64, 64), (1, 64, 128, 128)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
     """CALayer (cod.py:415-431) + the CAB residual (cod.py:451) against the plain torch composition in fp32."""
     R = C // 4
@@ -269,12 +276,13 @@ def _conv_ref(x, w, b, relu):
 @pytest.mark.parametrize("B,C,Co,H,W", [(2, 24, 24, 32, 32), (1, 24, 24, 40, 48), (2, 32, 32, 16, 16), (2, 64, 64, 32, 32),
                                          (1, 96, 96, 64, 64), (2, 24, 64, 128, 128), (3, 64, 32, 24, 32), (8, 24, 24, 128, 128)])
 @pytest.mark.parametrize("relu,bias", [(True, True), (False, False)])
-def test_conv3x3_single_fwd_bwd(dgtd, B, C, Co, H, W, relu, bias):
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_conv3x3_single_fwd_bwd(dgtd, B, C, Co, H, W, relu, bias, half):
     """One convolution: forward, input gradient (through the fused ReLU mask), weight and bias gradients vs fp32 torch."""
-    x = _rand(B, C, H, W, seed=1, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (_rand(Co, C, 3, 3, seed=2) / math.sqrt(9 * C)).to(torch.bfloat16)
-    b = (0.1 * _rand(Co, seed=3)).to(torch.bfloat16) if bias else None
-    g = _rand(B, Co, H, W, seed=4, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = _rand(B, C, H, W, seed=1, dtype=half).contiguous(memory_format=torch.channels_last)
+    w = (_rand(Co, C, 3, 3, seed=2) / math.sqrt(9 * C)).to(half)
+    b = (0.1 * _rand(Co, seed=3)).to(half) if bias else None
+    g = _rand(B, Co, H, W, seed=4, dtype=half).contiguous(memory_format=torch.channels_last)
     xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
     br = b.float().requires_grad_() if bias else None
     ref = _conv_ref(xr, wr, br, relu)
@@ -282,7 +290,7 @@ def test_conv3x3_single_fwd_bwd(dgtd, B, C, Co, H, W, relu, bias):
     xs, wsn = x.clone().requires_grad_(), w.clone().requires_grad_()
     bs = b.clone().requires_grad_() if bias else None
     y = dgtd.ops.conv3x3(xs, wsn, bs, relu)
-    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert y.shape == ref.shape and y.dtype == half
     torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
     # the ReLU mask is taken from the bf16 output: compare gradients where the fp32 reference is not within rounding of 0
     got = torch.autograd.grad(y, (xs, wsn) + ((bs,) if bias else ()), g)
@@ -297,13 +305,14 @@ def test_conv3x3_single_fwd_bwd(dgtd, B, C, Co, H, W, relu, bias):
 
 
 @pytest.mark.parametrize("shared", [True, False])
-def test_conv3x3_stack_matches_separate_convs(dgtd, shared):
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_conv3x3_stack_matches_separate_convs(dgtd, shared, half):
     """Z = 5 convolutions in one launch (shared or own inputs) == Z separate fp32 convolutions, incl. the summed shared-input grad."""
     Z, B, C, H, W = 5, 2, 24, 32, 48
-    xs = [_rand(B, H, W, C, seed=10 + z, dtype=torch.bfloat16) for z in range(1 if shared else Z)]
-    ws = [(_rand(C, C, 3, 3, seed=20 + z) / math.sqrt(9 * C)).to(torch.bfloat16).requires_grad_() for z in range(Z)]
-    bs = [(0.1 * _rand(C, seed=30 + z)).to(torch.bfloat16).requires_grad_() for z in range(Z)]
-    g = _rand(Z, B, H, W, C, seed=5, dtype=torch.bfloat16)
+    xs = [_rand(B, H, W, C, seed=10 + z, dtype=half) for z in range(1 if shared else Z)]
+    ws = [(_rand(C, C, 3, 3, seed=20 + z) / math.sqrt(9 * C)).to(half).requires_grad_() for z in range(Z)]
+    bs = [(0.1 * _rand(C, seed=30 + z)).to(half).requires_grad_() for z in range(Z)]
+    g = _rand(Z, B, H, W, C, seed=5, dtype=half)
     xin = (xs[0] if shared else torch.stack(xs)).clone().requires_grad_()
     y = dgtd.ops.conv3x3_stack(xin, ws, bs, True)
     assert y.shape == (Z, B, H, W, C)
@@ -328,7 +337,7 @@ def test_conv3x3_stack_matches_separate_convs(dgtd, shared):
 @pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 32, 16, 16, 32, 32), (2, 32, 16, 16, 64, 64), (1, 64, 24, 20, 48, 40), (2, 32, 128, 128, 64, 64),
                                              (2, 8, 7, 9, 19, 13), (1, 96, 32, 32, 64, 64), (2, 24, 2, 2, 16, 16), (1, 24, 16, 16, 128, 128), (2, 8, 3, 5, 40, 33)])
 @pytest.mark.parametrize("align", [True, False])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_bilinear_resize_nhwc(dgtd, B, C, Hi, Wi, Ho, Wo, align, dtype):
     """Forward and gather-backward vs F.interpolate in fp32 (x2, x4, x0.5 and a ragged non-integer ratio)."""
     x = _rand(B, C, Hi, Wi, seed=1, dtype=dtype).contiguous(memory_format=torch.channels_last)
@@ -347,7 +356,7 @@ def test_bilinear_resize_nhwc(dgtd, B, C, Hi, Wi, Ho, Wo, align, dtype):
 
 # ---------------------------------------------------------------------------------------------- Linear fused with its consumer
 @pytest.mark.parametrize("rows,K,N", [(1024, 128, 512), (8192, 512, 2048), (300, 64, 256)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_linear_gelu_fused_backward(dgtd, rows, K, N, dtype):
     """gelu(x W^T + b): value, dx, dW and the bias gradient (GELU' fused with the column sum) vs fp32 torch."""
     x = _rand(2, rows // 2, K, seed=1, dtype=dtype)
@@ -368,7 +377,7 @@ def test_linear_gelu_fused_backward(dgtd, rows, K, N, dtype):
 
 
 @pytest.mark.parametrize("rows,K,N", [(1024, 512, 128), (8192, 2048, 512), (300, 256, 64)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("with_s,with_g", [(True, True), (True, False), (False, False)])
 def test_linear_residual_fused_backward(dgtd, rows, K, N, dtype, with_s, with_g):
     """x + s*gamma*(h W^T + b): value and every gradient (dh, dW, db, dx, dgamma) vs fp32 torch."""
@@ -402,7 +411,7 @@ def test_linear_residual_fused_backward(dgtd, rows, K, N, dtype, with_s, with_g)
 
 
 @pytest.mark.parametrize("C", [64, 320, 512])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_layernorm_fork_adds_skip_gradient(dgtd, C, dtype):
     """(LN(x), x): the gradient of the skip branch is added inside the LayerNorm backward; result == autograd's separate add."""
     rows = 1000
@@ -428,7 +437,7 @@ def test_layernorm_fork_adds_skip_gradient(dgtd, C, dtype):
 
 
 @pytest.mark.parametrize("K,C,H", [(7, 128, 16), (7, 512, 12), (3, 256, 10)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_dwconv_fork_adds_skip_gradient(dgtd, K, C, H, dtype):
     """(dwconv(x), x): the skip-branch gradient is added inside the input-gradient convolution (mode 3)."""
     x = _rand(2, H, H, C, seed=1, dtype=dtype)
@@ -446,3 +455,39 @@ def test_dwconv_fork_adds_skip_gradient(dgtd, K, C, H, dtype):
     torch.testing.assert_close(hx.float(), gx, atol=tol, rtol=tol)
     torch.testing.assert_close(hw.float(), gw, atol=tol * 8, rtol=5e-2)
     torch.testing.assert_close(hb.float(), gb, atol=tol * 8, rtol=5e-2)
+
+
+# ---------------------------------------------------------------------------------------------- depthwise convs at the benchmarked shapes
+# the depthwise family is the largest dgtd time category of the bf16 step and had no direct op test at the shapes the
+# bench runs.  (K, gelu, B, H, W, C): ConvNeXt dw7x7 at stage 3 (LDS-tiled path with the XCD remap) and stage 1, Mlp dw3x3 + bias +
+# erf-GELU (modes 1 and 2) at PVT stage 1 (hidden 512 @128^2), stage 2 (1024 @64^2) and stage 4 (2048 @16^2), plus a ragged map.
+DW_SHAPES = [(7, False, 8, 32, 32, 512), (7, False, 8, 128, 128, 128), (3, True, 8, 128, 128, 512), (3, True, 8, 64, 64, 1024),
+             (3, True, 8, 16, 16, 2048), (7, False, 2, 20, 12, 256), (3, True, 3, 10, 14, 128)]
+
+
+@pytest.mark.parametrize("K,gelu,B,H,W,C", DW_SHAPES, ids=[f"k{s[0]}{'g' if s[1] else ''}_{s[2]}x{s[3]}x{s[4]}x{s[5]}" for s in DW_SHAPES])
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_dwconv_benchmarked_shapes_vs_fp32_torch(dgtd, K, gelu, B, H, W, C, half):
+    """dgtd_dwconv_fwd modes 0/1/2 (bias + polynomial-erfc GELU and its backward), the input gradient (flipped filter) and
+    dgtd_dwconv_bwd_weight for both K, in the 16-bit dtypes, against fp32 F.conv2d (+ exact erf GELU) on the same rounded inputs."""
+    if half == torch.float16 and not dgtd.ops._native.ENABLED:
+        pytest.skip("fp16 at the large shapes runs through one binding layer (same C ABI)")
+    x = _rand(B, H, W, C, seed=1, dtype=half)
+    w = (_rand(C, 1, K, K, seed=2) / K).to(half).requires_grad_()
+    b = (0.1 * _rand(C, seed=3)).to(half).requires_grad_()
+    g = _rand(B, H, W, C, seed=4, dtype=half)
+    xr, wr, br = x.float().requires_grad_(), w.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    pre = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=K // 2, groups=C).permute(0, 2, 3, 1)
+    ref = F.gelu(pre) if gelu else pre
+    gx, gw, gb = torch.autograd.grad(ref, (xr, wr, br), g.float())
+    xs = x.clone().requires_grad_()
+    y = dgtd.ops.dwconv_nhwc(xs, w, b, gelu)
+    hx, hw, hb = torch.autograd.grad(y, (xs, w, b), g)
+    assert y.dtype == half and hw.dtype == half
+    torch.testing.assert_close(y.float(), ref, atol=3e-2, rtol=2e-2)
+    # dx sums K*K taps of 16-bit-rounded du: absolute error grows with sqrt(K*K)
+    torch.testing.assert_close(hx.float(), gx, atol=2e-2 * K, rtol=3e-2)
+    n = B * H * W
+    assert (hw.float() - gw).norm() / gw.norm() < 2e-2, "weight gradient"
+    assert (hb.float() - gb).norm() / gb.norm() < 2e-2, "bias gradient"
+    torch.testing.assert_close(hw.float(), gw, atol=3e-2 * math.sqrt(n), rtol=5e-2)
