@@ -428,7 +428,7 @@ class ShapePropDecoder(nn.Module):
             else:
                 y = F.conv2d(h, w, b, padding=1)
         elif s_ in (2, 4, 8) and Hin == H * s_ and h.shape[-1] == W * s_:
-            w4 = F.avg_pool2d(w, 2, stride=1, padding=1)   # mean of the four shifted 3x3 kernels (zero padded), one launch
+            w4 = _fold_2x2_mean(w)                 # mean of the four shifted 3x3 kernels (zero padded), one launch
             off = s_ // 2 - 2                      # first input row/col of the 4x4 window of output 0
             if off < 0:
                 y = F.conv2d(h, w4, b, stride=s_, padding=-off)
@@ -437,6 +437,31 @@ class ShapePropDecoder(nn.Module):
         else:                                      # any other geometry: the literal reference sequence
             y = F.interpolate(F.conv2d(h, w, b, padding=1), size=(H, W), mode="bilinear", align_corners=False)
         return _nchw_to_tokens(y)
+
+
+_FOLD = {}
+
+
+def _fold_2x2_mean(w: torch.Tensor) -> torch.Tensor:
+    """[O,I,3,3] -> [O,I,4,4]: w4[a,b] = mean_{h in {a-1,a}, v in {b-1,b}} w[h,v] (zero outside) = the kernel of `mean of the 2x2
+    centre pixels of conv3x3(.)` as ONE 4x4 convolution.  Written as a constant [16,9] matrix applied to the taps (a batched GEMM
+    over the output channels; both views are free for the O,H,W,I storage the gradient reducer gives these weights).
+    NOT F.avg_pool2d(w, 2, 1, 1): on ROCm 7.2 / torch 2.10 its BACKWARD is wrong for channels_last inputs (max error 2.3 on N(0,1)
+    data, tools/debug_prompt_tail.py) - with the reducer's channels_last weights that corrupted these 13 weight gradients."""
+    key = (w.device, w.dtype)
+    T = _FOLD.get(key)
+    if T is None:
+        T = torch.zeros(16, 9)
+        for a in range(4):
+            for b in range(4):
+                for hh in (a - 1, a):
+                    for v in (b - 1, b):
+                        if 0 <= hh < 3 and 0 <= v < 3:
+                            T[a * 4 + b, hh * 3 + v] = 0.25
+        T = _FOLD[key] = T.to(device=w.device, dtype=w.dtype)
+    O, I = w.shape[:2]
+    w4 = torch.matmul(T, w.permute(0, 2, 3, 1).reshape(O, 9, I))      # [O,16,I]
+    return w4.view(O, 4, 4, I).permute(0, 3, 1, 2)                    # logical [O,I,4,4] in channels_last memory
 
 
 class prompt_decoder(nn.Module):

@@ -59,3 +59,19 @@ def test_drop_path_plan_and_state_dict_contract():
     net.eval()
     net._draw_drop_path(4)
     assert net._dp_plan["masks"] is None
+
+
+def test_fold_2x2_mean_matches_avg_pool_and_its_gradient():
+    """The [16,9] tap matrix == F.avg_pool2d(w, 2, 1, 1) (value and gradient; CPU, where avg_pool2d's backward is right), for a
+    contiguous and a channels_last weight."""
+    from dgtd.nn.modules import _fold_2x2_mean
+    w = torch.randn(10, 24, 3, 3)
+    g = torch.randn(10, 24, 4, 4)
+    for cl in (False, True):
+        a = (w.contiguous(memory_format=torch.channels_last) if cl else w).clone(memory_format=torch.preserve_format).requires_grad_()
+        b = w.clone().requires_grad_()
+        ya, yb = _fold_2x2_mean(a), F.avg_pool2d(b, 2, stride=1, padding=1)
+        torch.testing.assert_close(ya, yb, rtol=1e-6, atol=1e-6)
+        ga, = torch.autograd.grad(ya, a, g)
+        gb, = torch.autograd.grad(yb, b, g)
+        torch.testing.assert_close(ga, gb, rtol=1e-6, atol=1e-6)

@@ -491,3 +491,29 @@ def test_dwconv_benchmarked_shapes_vs_fp32_torch(dgtd, K, gelu, B, H, W, C, half
     assert (hw.float() - gw).norm() / gw.norm() < 2e-2, "weight gradient"
     assert (hb.float() - gb).norm() / gb.norm() < 2e-2, "bias gradient"
     torch.testing.assert_close(hw.float(), gw, atol=3e-2 * math.sqrt(n), rtol=5e-2)
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+@pytest.mark.parametrize("half", [torch.float32] + HALVES, ids=str)
+def test_prompt_tail_weight_gradient_with_channels_last_weights(dgtd, scale, half):
+    """Round-2 finding: the folded prompt-decoder tail (ShapePropDecoder.forward_tokens, cod.py:1224-1226 + :1471) used
+    F.avg_pool2d on the 3x3 weight, whose BACKWARD is wrong on ROCm for channels_last inputs - exactly the storage the gradient
+    reducer gives these weights.  The weight gradient of the production formulation, with the weight as a channels_last leaf, against
+    the literal fp32 sequence conv3x3 -> bilinear."""
+    C, S = 128, 32
+    dec = dgtd.nn.ShapePropDecoder(C, 24).cuda()
+    conv = dec.decoder[4]
+    h = _rand(2, 24, S, S, seed=1).relu()
+    H = S // scale
+    w32 = conv.weight.detach().clone().requires_grad_()
+    ref = F.interpolate(F.conv2d(h, w32, conv.bias, padding=1), size=(H, H), mode="bilinear", align_corners=False)
+    gout = _rand(*ref.shape, seed=2)
+    gw_ref, = torch.autograd.grad(ref, w32, gout)
+    w = conv.weight.detach().to(half).contiguous(memory_format=torch.channels_last).clone(memory_format=torch.preserve_format).requires_grad_()
+    conv._w, conv._b = w, conv.bias.detach().to(half)
+    hh = h.to(half).contiguous(memory_format=torch.channels_last)
+    y = dec.forward_tokens(None, H, H, trunk=hh.permute(0, 2, 3, 1))
+    g, = torch.autograd.grad(y, w, gout.flatten(2).transpose(1, 2).to(y.dtype))
+    torch.testing.assert_close(y.float(), ref.flatten(2).transpose(1, 2), atol=2e-5 if half == torch.float32 else 3e-2, rtol=3e-2)
+    rel = float((g.float() - gw_ref).norm() / gw_ref.norm())
+    assert rel < (1e-4 if half == torch.float32 else 1e-2), rel
