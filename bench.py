@@ -18,7 +18,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")   # before torch loads MIOpen; see <package>/__init__.py (fp32 accuracy; the bf16 step has no Winograd-eligible library conv)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

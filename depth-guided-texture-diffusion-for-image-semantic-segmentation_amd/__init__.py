@@ -11,6 +11,8 @@ import os as _os
 # relative accuracy per call; through the cancelling gradient sums of this model that showed as 10x larger parameter-gradient errors
 # against an fp64 oracle than the CPU fp32 path has (tools/debug_fp32_grad_error.py: median 1.6e-2 -> 1.7e-3 with Winograd off).
 # The 16-bit modes run their 3x3 stride-1 convolutions on dgtd_conv3x3_* and are not affected.  Set MIOPEN_DEBUG_CONV_WINOGRAD=1 to undo.
+# MIOpen reads its environment when the library is LOADED (at `import torch`): the setting below only takes effect when this package is
+# imported before torch; bench.py, tests/conftest.py and __graft_entry__.smoke() set it before importing torch for that reason.
 _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
 
 from . import _lib  # noqa: F401

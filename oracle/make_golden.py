@@ -188,6 +188,29 @@ def gen_model(S: int, B: int, with_grads: bool) -> dict:
     return out
 
 
+FP64_KEYS = ("prompt_encoder.propagation_weight_regressor.reg.", "prompt_encoder.encoder1.", "prompt_encoder.message_passing.conv.",
+             "prompt_encoder.encoder2.downsample_layers.0.", "patch_embed1.proj.")
+
+
+def gen_grads_fp64(S: int = 64, B: int = 2) -> dict:
+    """The REAL reference in float64 (train mode, DropPath 0) on the model64 inputs: gradients of the parameters that sit upstream of
+    both trunks (diffuser front end, ConvNeXt stem, first patch embed).  fp64 truth for the question "which fp32 implementation is
+    the inaccurate one" (VERDICT r1 weak #4): the same reference in fp32 is stored beside it."""
+    out = {}
+    x, d, l = filler.synthetic_batch(B, S)
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        net = ref_loader.build_reference_model(S, train=True)
+        filler.fill_module(net)
+        net = net.to(dt)
+        loss = net(None, x.to(dt), l.to(dt), list(d.to(dt)), mode="loss")["loss"]
+        loss.backward()
+        out[f"loss.{tag}"] = np.float64(loss.item())
+        for k, p in net.named_parameters():
+            if p.grad is not None and any(f in k for f in FP64_KEYS):
+                out[f"{tag}.{k}"] = p.grad.numpy()
+    return out
+
+
 def gen_msda() -> dict:
     """The reference's own ms_deform_attn_core_pytorch (twig/ops/functions/ms_deform_attn_func.py:49-71), imported with an empty stub
     for the compiled MultiScaleDeformableAttention module, on the deterministic cases of oracle/ms_deform_attn_cpu.py."""
@@ -238,7 +261,9 @@ def main(argv):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     if not argv or "preprocess" in argv:
         np.savez_compressed(os.path.join(GOLDEN_DIR, "preprocess.npz"), **gen_preprocess())
-    want = set(argv) or {"modules", "model64", "model256", "msda"}
+    want = set(argv) or {"modules", "model64", "model256", "msda", "grads64_fp64"}
+    if "grads64_fp64" in want:
+        np.savez_compressed(os.path.join(GOLDEN_DIR, "grads64_fp64.npz"), **gen_grads_fp64())
     if "msda" in want:
         np.savez_compressed(os.path.join(GOLDEN_DIR, "msda.npz"), **gen_msda())
     if "modules" in want:

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# before anything imports torch (MIOpen reads its environment when the library is loaded): fp32 Winograd convolutions off, see
+# <package>/__init__.py.  fp32 is the parity mode; the 16-bit modes do not reach MIOpen for 3x3 stride-1 convolutions.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -332,7 +332,9 @@ def test_fp32_gradients_match_reference_element_fingerprints(pair64):
         if norms[i] < 0:
             continue
         gr = params[k].grad
-        tol = 2e-2 if ("prompt_encoder.encoder1." in k or "prompt_encoder.message_passing.conv." in k) else 3e-3
+        # the reference's OWN fp32 run is 0.2-0.9 % away from its fp64 run for the parameters upstream of the trunks
+        # (tests/golden/grads64_fp64.npz): the golden fingerprints of the texture-diffuser tensors carry that noise themselves
+        tol = 2e-2 if "prompt_encoder." in k else 3e-3
         got_s = grad_samples(gr)
         got_p = grad_projection(gr)
         # a permuted / transposed / sign-flipped gradient is off by O(1) of its typical element: 2 % of max(sample, rms element)
@@ -347,30 +349,34 @@ def test_fp32_gradients_match_reference_element_fingerprints(pair64):
     filler.fill_module(net)
 
 
-def test_cancelling_diffuser_gradients_against_fp64_oracle(dgtd):
-    """three diffuser parameters get 2e-2 instead of 2e-3 in the norm test because their gradient is a signed
-    sum over every pixel that cancels to ~1e-3 of its terms.  Settle it with an fp64 oracle: the HIP fp32 gradient must be no
-    further from the fp64 truth than a small multiple of what the fp32 CPU oracle (oneDNN) itself is."""
-    S, B = 32, 2                                             # fp64 on the host cores: keep it small
-    (x, d, l), _, g64 = _oracle_grads(S, B, seed=0, dtype=torch.float64)
-    _, _, g32 = _oracle_grads(S, B, seed=0, dtype=torch.float32)
+def test_upstream_gradients_against_fp64_reference(dgtd):
+    """the diffuser parameters got 2e-2 instead of 2e-3 in the norm test.  Settled with the REAL reference run in
+    float64 (tests/golden/grads64_fp64.npz, oracle/make_golden.py): element-wise relative L2 of the HIP fp32 gradients of every
+    parameter upstream of both trunks vs the fp64 truth, beside the same figure for the reference's own fp32 CPU run.  Finding
+    (tools/debug_fp32_grad_error.py): the gap was MIOpen's fp32 Winograd convolutions (median error over all tensors 1.6e-2 with,
+    1.7e-3 without); with them off (tests/conftest.py) the HIP path is as close to the truth as the CPU fp32 path is."""
+    g = np.load(os.path.join(GOLDEN_DIR, "grads64_fp64.npz"))
     net = dgtd.nn.cod(drop_path_rate=0.0)
     filler.fill_module(net)
     net = net.cuda().train()
-    net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"].backward()
+    x, d, l = filler.synthetic_batch(2, 64)
+    loss = net(None, x.cuda(), l.cuda(), d.cuda(), mode="loss")["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss.f64"])) < 1e-4
     params = dict(net.named_parameters())
-    keys = [k for k in g64 if "prompt_encoder.encoder1." in k or "prompt_encoder.message_passing.conv." in k or "propagation_weight_regressor" in k]
-    assert len(keys) == 6
+    keys = [k[4:] for k in g.files if k.startswith("f64.")]
+    assert len(keys) >= 10
     report = {}
     for k in keys:
-        truth = g64[k]
+        truth = torch.from_numpy(g["f64." + k])
         e_hip = float((params[k].grad.double().cpu() - truth).norm() / truth.norm())
-        e_cpu = float((g32[k].double() - truth).norm() / truth.norm())
+        e_cpu = float((torch.from_numpy(g["f32." + k]).double() - truth).norm() / truth.norm())
         report[k] = (e_hip, e_cpu)
-        # both fp32 paths sit at the same distance from the truth (the error is fp32 re-association amplified by the cancellation,
-        # not a defect of either implementation); 5e-3 absolute covers the amplification measured on both
-        assert e_hip <= max(4.0 * e_cpu, 5e-3), (k, e_hip, e_cpu)
-    print("fp64-referenced relative errors (hip, cpu-fp32):", report)
+    print("relative L2 vs fp64 (hip fp32, reference cpu fp32):")
+    for k, v in report.items():
+        print(f"  {k}: {v[0]:.3e} {v[1]:.3e}")
+    for k, (e_hip, e_cpu) in report.items():
+        assert e_hip <= max(10.0 * e_cpu, 2e-3), (k, e_hip, e_cpu)
 
 
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16], ids=str)
