@@ -170,16 +170,28 @@ def gen_model(S: int, B: int, with_grads: bool) -> dict:
         loss = net(None, x, l, list(d), mode="loss")["loss"]
         out["train.loss"] = np.float64(loss.item())
         loss.backward()
-        names, norms, samples, projs = [], [], [], []
+        names, norms = [], []
         for k, p in net.named_parameters():
             names.append(k)
             norms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+        out["train.grad_names"] = np.array(names)
+        out["train.grad_norms"] = np.array(norms, dtype=np.float64)          # the reference as it runs: fp32
+        # The same reference in float64.  Its fp32 gradients are 0.2-0.9 % (some ConvNeXt tensors 2 %) away from these for everything
+        # upstream of the trunks (oneDNN's fp32 convolutions + cancelling sums), so element-level checks use the fp64 values:
+        # norms, 16 strided samples in logical (O,I,H,W) element order and the dot product with a fixed +-1 pattern (a transposed /
+        # permuted / sign-flipped gradient keeps its norm but not these)
+        net64 = ref_loader.build_reference_model(S, train=True)
+        filler.fill_module(net64)
+        net64 = net64.double()
+        loss64 = net64(None, x.double(), l.double(), list(d.double()), mode="loss")["loss"]
+        loss64.backward()
+        out["train.loss64"] = np.float64(loss64.item())
+        norms64, samples, projs = [], [], []
+        for k, p in net64.named_parameters():
+            norms64.append(-1.0 if p.grad is None else p.grad.norm().item())
             samples.append(np.zeros(GRAD_SAMPLES, np.float32) if p.grad is None else grad_samples(p.grad))
             projs.append(0.0 if p.grad is None else grad_projection(p.grad))
-        out["train.grad_names"] = np.array(names)
-        out["train.grad_norms"] = np.array(norms, dtype=np.float64)
-        # element-level fingerprints (a transposed / permuted / sign-flipped gradient keeps its norm): strided samples in the logical
-        # (O,I,H,W) element order and the dot product with a fixed +-1 pattern
+        out["train.grad_norms64"] = np.array(norms64, dtype=np.float64)
         out["train.grad_samples"] = np.stack(samples)
         out["train.grad_proj"] = np.array(projs, dtype=np.float64)
         bn = {k: v for k, v in net.state_dict().items() if "running_" in k}

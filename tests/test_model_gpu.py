@@ -325,24 +325,24 @@ def test_fp32_gradients_match_reference_element_fingerprints(pair64):
     net.zero_grad(set_to_none=True)
     net(None, x, l, d, mode="loss")["loss"].backward()
     names = g["train.grad_names"].tolist()
-    norms, samples, projs = g["train.grad_norms"], g["train.grad_samples"], g["train.grad_proj"]
+    norms, samples, projs = g["train.grad_norms64"], g["train.grad_samples"], g["train.grad_proj"]
     params = dict(net.named_parameters())
     bad = []
     for i, k in enumerate(names):
         if norms[i] < 0:
             continue
         gr = params[k].grad
-        # the reference's OWN fp32 run is 0.2-0.9 % away from its fp64 run for the parameters upstream of the trunks
-        # (tests/golden/grads64_fp64.npz): the golden fingerprints of the texture-diffuser tensors carry that noise themselves
-        tol = 2e-2 if "prompt_encoder." in k else 3e-3
+        # fingerprints come from the reference run in float64 (the fp32 reference itself is up to 2 % away from it); the HIP fp32 path
+        # sits within ~1e-5 of the fp64 truth (test_upstream_gradients_against_fp64_reference), so 1e-3 on the scale of the tensor's
+        # rms element / norm is generous for rounding and far below what a permuted / transposed / sign-flipped gradient shows (O(1))
         got_s = grad_samples(gr)
         got_p = grad_projection(gr)
-        # a permuted / transposed / sign-flipped gradient is off by O(1) of its typical element: 2 % of max(sample, rms element)
-        # separates that from fp32 summation noise on single elements (each is a sum over every token of the map); the projection is
-        # a signed sum of n terms of size ~norm/sqrt(n) and is compared on the scale of the gradient norm
         rms = norms[i] / np.sqrt(gr.numel())
         e_s, e_p = float(np.abs(got_s - samples[i]).max()), abs(got_p - float(projs[i]))
-        if e_s > 2e-2 * max(float(np.abs(samples[i]).max()), rms) + 1e-7 or e_p > tol * norms[i] + 1e-7:
+        # 1e-6 absolute: a few gradients are exactly 0 in exact arithmetic (a bias in front of a train-mode BatchNorm: norm4.bias) and
+        # pure rounding noise in any floating-point run
+        if e_s > 1e-3 * max(float(np.abs(samples[i]).max()), rms) + 1e-6 or e_p > 1e-3 * norms[i] + 1e-6 \
+                or abs(float(gr.double().norm()) - norms[i]) > 1e-3 * norms[i] + 1e-6:
             bad.append(f"{k}: sample err {e_s:.3e} (rms element {rms:.3e}), projection {got_p:.6e} vs {float(projs[i]):.6e}, norm {norms[i]:.3e}")
     assert GRAD_SAMPLES == samples.shape[1]
     assert not bad, "\n".join(bad[:8])
