@@ -6,8 +6,10 @@
 One "step" = forward + loss + backward + gradient all-reduce (RCCL, N>1) + AdamW update, batch 8 per GPU
 (BASELINE.json configs[1]: config/sod.yml model, 512x512, batch 8, bf16).  Rank 0 prints ONE JSON line.
 Inputs are resident in HBM before the timed region.  After the timed region a separate instrumented pass times
-every hand-written kernel with HIP events on its launch stream (roofline), and rank 0 at N=1 times the CPU
-oracle on a bounded sample (cpu_baseline).
+every C-ABI call with HIP events on its launch stream inside libdgtd.so (roofline; attention MFMA utilisation), and
+rank 0 at N=1 reports the mIoU parity pair (HIP vs CPU oracle) and times the CPU oracle on a bounded sample (cpu_baseline).
+Other BASELINE configs: --backbone pvt_v2_b3 (config 3's per-GPU workload), --mode predict --size 1024 --batch 4 --dtype f32
+(config 4), --dtype f16 --batch 16 (config 5's per-GPU workload: fp16 + fp32 masters + dynamic loss scale).
 """
 from __future__ import annotations
 
@@ -25,7 +27,8 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"hbm": (8000.0, "GB/s"), "mfma_bf16": (2500.0, "TFLOP/s"), "mfma_f32": (157.3, "TFLOP/s")}  # MI355X_MICROARCH.md
+PEAK = {"hbm": (8000.0, "GB/s"), "mfma_bf16": (2500.0, "TFLOP/s"), "mfma_f16": (2500.0, "TFLOP/s"), "mfma_f32": (157.3, "TFLOP/s")}  # MI355X_MICROARCH.md
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
 def parse():
@@ -35,14 +38,22 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="bf16: throughput mode; f16: the reference's AMP recipe (fp16 + fp32 masters + dynamic loss scale, BASELINE config 5); f32: parity mode")
+    ap.add_argument("--mode", default="train", choices=["train", "predict"],
+                    help="predict: eval-mode inference throughput (BASELINE config 4: --mode predict --size 1024 --batch 4 --dtype f32)")
+    ap.add_argument("--backbone", default="pvt_v2_b2", help="pvt_v2_b3 = the tier-B backbone of BASELINE config 3")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="train mode: replay the step as a captured hipGraph (auto: try, fall back to the eager step if capture fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-miou", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
     return ap.parse_args()
 
 
-def cpu_baseline(size: int, log=lambda m: None):
-    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+def cpu_baseline(size: int, batch: int, mode: str, log=lambda m: None):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload: the same batch size, one
+    untimed step, then at least two timed steps / 15 s."""
     from oracle import cod_cpu
     try:
         avail = len(os.sched_getaffinity(0))
@@ -50,22 +61,63 @@ def cpu_baseline(size: int, log=lambda m: None):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))   # the GPU box grants a 16-core share per GPU; more threads only oversubscribe
     torch.set_num_threads(cores)
-    B = 1
-    net = cod_cpu.cod(size).train()
+    B = batch
+    net = cod_cpu.cod(size)
+    net = net.train() if mode == "train" else net.eval()
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 3, size, size, generator=g)
     d = torch.rand(B, 1, size, size, generator=g)
     l = (torch.rand(B, 1, size, size, generator=g) > 0.5).float()
+
+    def one():
+        if mode == "train":
+            net.zero_grad(set_to_none=True)
+            net(None, x, l, d, mode="loss")["loss"].backward()
+        else:
+            with torch.no_grad():
+                net(None, x, l, d, mode="predict")
+    one()                                                    # untimed: allocator, oneDNN primitive caches
     steps, t0 = 0, time.perf_counter()
-    while steps < 3 or time.perf_counter() - t0 < 12.0:      # ~12-20 s of CPU work
-        net.zero_grad(set_to_none=True)
-        loss = net(None, x, l, d, mode="loss")["loss"]
-        loss.backward()
+    while steps < 2 or time.perf_counter() - t0 < 15.0:      # ~15-30 s of CPU work
+        one()
         steps += 1
         log(f"cpu oracle step {steps}: {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
+    what = "fwd+loss+bwd" if mode == "train" else "eval forward (predict)"
     return {"value": steps * B / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps fwd+loss+bwd of oracle/cod_cpu.py, {size}x{size}, batch {B}, fp32, {cores} torch threads, {dt:.1f} s"}
+            "sample": f"{steps} steps {what} of oracle/cod_cpu.py, {size}x{size}, batch {B}, fp32, {cores} torch threads, {dt:.1f} s (after 1 untimed step)"}
+
+
+def miou_parity(dgtd, dev, n: int = 256, size: int = 64, bs: int = 32, log=lambda m: None):
+    """north_star "mIoU within 0.1 of reference on identical weights" (SURVEY 8(d)): binary 2-class mIoU of (sigmoid > 0.5) vs the
+    label by ONE routine on the CPU oracle's and the HIP path's predict outputs over the same n synthetic samples with the
+    deterministic filler weights, plus the reference's own mean_iou (twig/metric/mIOU.py:32-58) restated: identically 1.0 for the
+    single-channel head on both sides.  Checker use of the oracle, outside the timed region."""
+    from oracle import cod_cpu, filler
+    M = dgtd.runner.metrics
+    ref = cod_cpu.cod(size).eval()
+    filler.fill_module(ref)
+    net = dgtd.nn.cod(drop_path_rate=0.0)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(dev).eval()
+    a, b, ra, rb = [], [], [], []
+    t0 = time.perf_counter()
+    for i in range(0, n, bs):
+        x, d, l = filler.synthetic_batch(bs, size, seed=5000 + i)
+        with torch.no_grad():
+            pw, _ = ref(None, x, l, d, mode="predict")
+            pg, _ = net(None, x.to(dev), l.to(dev), d.to(dev), mode="predict")
+        pg = pg.cpu()
+        for j in range(bs):
+            a.append(M.binary_miou(pw[j:j + 1], l[j:j + 1]))
+            b.append(M.binary_miou(pg[j:j + 1], l[j:j + 1]))
+        ra.append(M.mean_iou_reference(pw, l))
+        rb.append(M.mean_iou_reference(pg, l))
+        log(f"mIoU parity: {i + bs}/{n} samples, {time.perf_counter() - t0:.1f} s")
+    ma, mb = 100.0 * sum(a) / len(a), 100.0 * sum(b) / len(b)
+    return {"binary_miou_oracle": round(ma, 4), "binary_miou_hip": round(mb, 4), "abs_diff_points": round(abs(ma - mb), 4),
+            "reference_mean_iou_oracle": sum(ra) / len(ra), "reference_mean_iou_hip": sum(rb) / len(rb), "samples": n,
+            "what": f"{n} synthetic {size}x{size} samples, filler weights, fp32 parity mode, predict path (cod.py:152-153, :219)"}
 
 
 def main():
@@ -91,33 +143,57 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = DTYPES[args.dtype]
+    train = args.mode == "train"
 
     torch.manual_seed(0)
-    net = dgtd.nn.cod(compute_dtype=dtype).to(dev).train()   # random init of the reference architecture, DropPath active
+    # random init of the reference architecture; DropPath active in train mode
+    net = dgtd.nn.cod(compute_dtype=dtype, backbone=args.backbone).to(dev)
+    net = net.train() if train else net.eval()
     dgtd.dist.broadcast_parameters(net)
     reducer = dgtd.dist.GradReducer(net, working_dtype=dtype)
     flat_opt = os.environ.get("DGTD_FLAT_ADAMW", "1") != "0"
-    # AdamW over the reducer's flat buckets (one launch per lr run, bf16 working copies rewritten in the same pass), or torch's
+    scaler = dgtd.runner.LossScaler(dev) if (train and dtype == torch.float16) else None   # AmpOptimWrapper's GradScaler (config/sod.yml:57)
+    # AdamW over the reducer's flat buckets (one launch per lr run, 16-bit working copies rewritten in the same pass), or torch's
     # fused multi-tensor AdamW + one cast per bucket
-    opt = dgtd.runner.FlatAdamW(reducer) if flat_opt else dgtd.runner.build_optimizer(net)
+    want_graph = train and args.graph != "off" and os.environ.get("DGTD_GRAPH", "1") != "0" and (flat_opt or scaler is not None)
+    opt = dgtd.runner.FlatAdamW(reducer, scaler=scaler, graph_safe=want_graph) if (flat_opt or scaler is not None) else dgtd.runner.build_optimizer(net)
     data = dgtd.runner.SyntheticRGBD(args.size, args.batch, rank=rank, device=dev)
     batches = [data.batch_at(i) for i in range(2)]  # resident in HBM before timing
 
-    def fwd_bwd(b):
+    def train_step(i):
+        b = batches[i % len(batches)]
         reducer.zero_grad()
         loss = net(b["raw"], b["input"], b["label"], b["depth"], mode="loss")["loss"]
-        loss.backward()
-        return loss
-
-    def step(i):
-        b = batches[i % len(batches)]
-        loss = fwd_bwd(b)
+        (scaler.scale(loss) if scaler is not None else loss).backward()
         reducer.finish()
         opt.step()
-        if not flat_opt:
+        if not isinstance(opt, dgtd.runner.FlatAdamW):
             reducer.refresh_working()
         return loss
+
+    def predict_step(i):
+        b = batches[i % len(batches)]
+        with torch.no_grad():
+            prob, _ = net(b["raw"], b["input"], b["label"], b["depth"], mode="predict")
+        return prob.mean()
+
+    step = train_step if train else predict_step
+    graphed = None
+    if want_graph:
+        try:
+            graphed = dgtd.runner.GraphedTrainStep(net, reducer, opt, scaler=scaler, warmup=2)
+            tg = time.perf_counter()
+            graphed.capture(batches[0])
+            step = lambda i: graphed(batches[i % len(batches)])
+            print(f"[bench] hipGraph capture of the training step: ok ({time.perf_counter() - tg:.1f} s)", file=sys.stderr, flush=True)
+        except Exception as e:  # the eager step stays available; say so in the result line
+            if args.graph == "on":
+                raise
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
+            reducer.overlap = getattr(graphed, "_overlap_before", reducer.overlap)
+            graphed = None
+            step = train_step
 
     def barrier():
         if world > 1:
@@ -149,12 +225,14 @@ def main():
         dt = t.item()
     final_loss = loss.item()
 
-    # ---- instrumented pass: per-kernel HIP-event timing (not part of `value`)
-    roofline, kernels = None, []
+    # ---- instrumented pass: per-call HIP-event timing inside libdgtd.so (not part of `value`)
+    roofline, kernels, attention = None, [], []
     if rank == 0 and args.profile_steps > 0:
-        # The step is host-bound, so an event pair around a launch would mostly time the host's enqueue gap.  Each
-        # instrumented step is therefore queued BEHIND a ballast of large GEMMs (about 2.5 step-times of device work): the
-        # host runs ahead, the launches and their event markers execute back to back, and the pairs measure device time.
+        # The timing lives in the C ABI (dgtd_profile_enable), so this pass runs EXACTLY the autograd nodes of the timed step (the
+        # C++ bindings and their fused nodes included).  The step is partly host-bound, so an event pair around a launch would also
+        # time the host's enqueue gap: each instrumented step is queued BEHIND a ballast of large GEMMs (about 2.5 step-times of
+        # device work), the host runs ahead, the launches and their event markers execute back to back, and the pairs measure
+        # device time.
         ball = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
         ball_out = torch.empty_like(ball)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -165,44 +243,49 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         n_ball = int(2.5 * (1e3 * dt / args.steps) / max(e0.elapsed_time(e1) / 4, 0.1)) + 1
-        dgtd._lib.PROFILER = dgtd._lib.Profiler()
+        dgtd._lib.profile_native(True)
+        prof_step = train_step if train else predict_step      # the eager step: a graph replay does not pass through the C ABI
         for i in range(args.profile_steps):
             for _ in range(n_ball):
                 torch.mm(ball, ball, out=ball_out)
-            step(i)
+            prof_step(i)
         del ball, ball_out
-        summ = dgtd._lib.PROFILER.summary()
+        summ = dgtd._lib.profile_native_summary()
+        dgtd._lib.profile_native(False)
         log("instrumented pass done")
-        dgtd._lib.PROFILER = None
+        mfma_peak = {torch.bfloat16: "mfma_bf16", torch.float16: "mfma_f16", torch.float32: "mfma_f32"}[dtype]
         for key, e in summ.items():
             if e["amount"] <= 0 or e["ms"] <= 0:
                 continue
             mfma = e["bound"] == "mfma"
-            peak, unit = PEAK[("mfma_bf16" if dtype == torch.bfloat16 else "mfma_f32") if mfma else "hbm"]
+            peak, unit = PEAK[mfma_peak if mfma else "hbm"]
             per_s = e["amount"] / (e["ms"] * 1e-3)
             achieved = per_s / 1e12 if mfma else per_s / 1e9
-            kernels.append({"kernel": key, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
-                            "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": e["calls"] / args.profile_steps,
-                            "avg_us": round(1e3 * e["ms"] / e["calls"], 2), "ms_per_step": round(e["ms"] / args.profile_steps, 3),
-                            "traffic": None})
-        # HBM bytes per launch measured offline with rocprofv3 PMC passes of the same kernels at the same shapes (tools/pmc_run.sh:
-        # FETCH_SIZE x2 + WRITE_SIZE in separate runs, MI355X_MICROARCH.md); null where no pass exists for that shape
+            rec = {"kernel": key, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
+                   "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": e["calls"] / args.profile_steps,
+                   "avg_us": round(1e3 * e["ms"] / e["calls"], 2), "ms_per_step": round(e["ms"] / args.profile_steps, 3),
+                   "traffic": None}
+            rec["algorithmic_flops" if mfma else "algorithmic_bytes"] = round(e["amount"] / e["calls"])
+            kernels.append(rec)
+        # HBM bytes per launch measured OFFLINE with rocprofv3 PMC passes of the same kernels at the same shapes (tools/pmc_run.sh:
+        # FETCH_SIZE x2 + WRITE_SIZE in separate runs, MI355X_MICROARCH.md), read from the committed profiles/; null where no pass exists
         pmc = {}
         for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_by_bench_key.json"))):
             try:
                 pmc.update(json.load(open(f)))
             except (OSError, ValueError):
                 pass
-        for k, e in zip(kernels, [summ[k_["kernel"]] for k_ in kernels]):
-            if k["bound"] == "hbm":
-                k["algorithmic_bytes"] = round(e["amount"] / e["calls"])
+        for k in kernels:
             k["traffic"] = pmc.get(k["kernel"])
         kernels.sort(key=lambda k: -k["ms_per_step"])
+        # MFMA utilisation of the attention GEMMs (QK^T and AV, and their gradients), every stage: flops / device time / dense peak
+        attention = [k for k in kernels if k["bound"] == "mfma"]
         if kernels:
             roofline = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE)"
-            if "algorithmic_bytes" in kernels[0]:
-                roofline["algorithmic_bytes"] = kernels[0]["algorithmic_bytes"]
+            roofline["traffic_source"] = "offline rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE), HBM bytes per launch"
+            for extra in ("algorithmic_bytes", "algorithmic_flops"):
+                if extra in kernels[0]:
+                    roofline[extra] = kernels[0][extra]
             roofline["kernel"] = kernels[0]["kernel"]
             roofline["avg_us"] = kernels[0]["avg_us"]
     if world > 1:
@@ -210,22 +293,34 @@ def main():
 
     if rank == 0:
         imgs = args.steps * args.batch * world
+        what = "fwd+loss+bwd+allreduce+AdamW" if train else "eval forward, predict mode"
+        flops_per_img = (786.7e9 if train else 262.2e9) * (args.size / 512) ** 2      # reference-algorithmic, pvt_v2_b2
         out = {
-            "metric": "training images/sec (512x512 RGB-D, bs=8 per GPU; fwd+loss+bwd+allreduce+AdamW)",
+            "metric": (f"training images/sec ({args.size}x{args.size} RGB-D, bs={args.batch} per GPU; {what})" if train
+                       else f"inference images/sec ({args.size}x{args.size} RGB-D, bs={args.batch} per GPU; {what})"),
             "value": round(imgs / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "per_gpu": round(imgs / dt / world, 3), "target_per_gpu": 40.0,
-            "config": {"workload": f"config/sod.yml model `cod` (PVTv2-b2 + ConvNeXt-B texture diffuser + Hitnet decoder), "
-                                   f"{args.size}x{args.size} RGB+depth, batch {args.batch}/GPU, random init, DropPath active",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+            "per_gpu": round(imgs / dt / world, 3), "target_per_gpu": 40.0 if train else None,
+            "config": {"workload": f"config/sod.yml model `cod` ({args.backbone} + ConvNeXt-B texture diffuser + Hitnet decoder), "
+                                   f"{args.size}x{args.size} RGB+depth, batch {args.batch}/GPU, random init, "
+                                   + ("DropPath active" if train else "eval mode, no_grad"),
+                       "mode": args.mode, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hip_graph": graphed is not None,
+                       "final_loss": round(final_loss, 4) if train else None,
                        "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2),
-                       "tflops_sustained": round(imgs / dt * 786.7e9 * (args.size / 512) ** 2 / 1e12, 2)},
-            "roofline": roofline, "kernels": kernels[:12],
+                       "reference_algorithmic_tflops": round(imgs / dt * flops_per_img / 1e12, 2),
+                       "loss_scale": scaler.get_scale() if scaler is not None else None},
+            "roofline": roofline, "kernels": kernels[:12], "attention_mfma": attention,
         }
+        if world == 1 and not args.no_miou:
+            log("mIoU parity (HIP vs CPU oracle, 256 synthetic samples) ...")
+            out["miou"] = miou_parity(dgtd, dev, log=log)
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(args.size, log)
+            del net, reducer, opt
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.mode, log)
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), file=result_out, flush=True)
     if torch.distributed.is_initialized():

@@ -20,6 +20,8 @@ _vp, _fp, _i, _i64, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "dgtd_version": (_i, []),
     "dgtd_last_error": (C.c_char_p, []),
+    "dgtd_profile_enable": (_i, [_i]),
+    "dgtd_profile_dump": (_i64, [C.c_char_p, _i64]),
     "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
     "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
     "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
@@ -48,7 +50,7 @@ SIGNATURES = {
     "dgtd_diffuse_tail_bwd_workspace": (_i64, [_i]),
     "dgtd_diffuse_tail_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
-    "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _vp]),
+    "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp]),
     "dgtd_found_inf": (_i, [_fp, _i64, _fp, _vp]),
     "dgtd_loss_scale_update": (_i, [_fp, _f, _f, _i, _vp]),
     "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -132,6 +134,31 @@ class Profiler:
 
 
 PROFILER = None
+
+
+def profile_native(on: bool) -> None:
+    """Per-call device timing INSIDE libdgtd.so (dgtd_profile_enable): unlike ``PROFILER`` above it sees the calls of both host binding
+    layers, i.e. the very autograd nodes the timed training step runs (C++ bindings included)."""
+    load().dgtd_profile_enable(1 if on else 0)
+
+
+def profile_native_summary() -> dict:
+    """{key: {calls, ms, amount, bound}} of every call recorded since profile_native(True)."""
+    lib = load()
+    torch.cuda.synchronize()
+    n = lib.dgtd_profile_dump(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.dgtd_profile_dump(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        key, bound, amount, ms = line.split("\t")
+        if float(ms) < 0:
+            continue
+        e = out.setdefault(key, {"calls": 0, "ms": 0.0, "amount": 0.0, "bound": bound})
+        e["calls"] += 1
+        e["ms"] += float(ms)
+        e["amount"] += float(amount)
+    return out
 
 
 def call(name: str, *args, algo=None, key=None):

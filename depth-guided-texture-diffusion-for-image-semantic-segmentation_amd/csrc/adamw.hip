@@ -23,9 +23,11 @@ __device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, 
 template <typename WT>
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, WT* __restrict__ w, int64_t n, int64_t head,
-                                                         AdamArgs a, const float* __restrict__ amp) {
+                                                         AdamArgs a, const float* __restrict__ amp, const float* __restrict__ lr_dev) {
   // amp = the loss scaler's device state { scale, growth_tracker, 1/scale, found_inf, steps taken } or NULL
+  // lr_dev = the learning rate in device memory (a captured hipGraph replays with whatever the schedule wrote there) or NULL
   float gs = 1.f;
+  if (lr_dev) a.lr = *lr_dev;
   if (amp) {
     if (amp[3] != 0.f) return;                              // overflowed step: parameters, moments and working copies stay as they are
     gs = amp[2];
@@ -96,7 +98,8 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth
 
 extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
                                    float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                                   const float* amp_state, dgtd_stream s) {
+                                   const float* amp_state, const float* lr_dev, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (w ? 30.0 : 28.0) * n, "dgtd_adamw_flat[n=%lld]", (long long)n);
   DGTD_REQUIRE(n > 0 && p && g && m && v, "adamw_flat: bad arguments");
   DGTD_REQUIRE(amp_state || (bias_correction1 > 0.f && bias_correction2 > 0.f), "adamw_flat: bias corrections must be positive");
   DGTD_REQUIRE(!w || DGTD_IS_HALF(w_dt), "adamw_flat: the working copy is bf16 or fp16, got dtype %d", (int)w_dt);
@@ -107,8 +110,8 @@ extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v,
   const int64_t head = std::min<int64_t>(n, ((16 - (int64_t)(ap % 16)) % 16) / 4);
   AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f / bias_correction1, 1.f / sqrtf(bias_correction2), (float)log((double)beta1), (float)log((double)beta2)};
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((n + 3) / 4 + 8, 256), 8192));
-  if (w_dt == DGTD_F16) hipLaunchKernelGGL(adamw_flat_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (f16_t*)w, n, head, a, amp_state);
-  else hipLaunchKernelGGL(adamw_flat_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)w, n, head, a, amp_state);
+  if (w_dt == DGTD_F16) hipLaunchKernelGGL(adamw_flat_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (f16_t*)w, n, head, a, amp_state, lr_dev);
+  else hipLaunchKernelGGL(adamw_flat_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)w, n, head, a, amp_state, lr_dev);
   DGTD_CHECK_LAUNCH("adamw_flat");
   return 0;
 }
@@ -116,10 +119,11 @@ extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v,
 extern "C" int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1, float beta2,
                                float eps, float weight_decay, float bias_correction1, float bias_correction2, dgtd_stream s) {
   return dgtd_adamw_flat_amp(p, g, m, v, w_bf16, DGTD_BF16, n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2,
-                             nullptr, s);
+                             nullptr, nullptr, s);
 }
 
 extern "C" int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * n, "dgtd_found_inf[n=%lld]", (long long)n);
   DGTD_REQUIRE(n > 0 && g && found, "found_inf: bad arguments");
   const uintptr_t ap = (uintptr_t)g;
   DGTD_REQUIRE(ap % 4 == 0, "found_inf: g must be 4-byte aligned");

@@ -489,6 +489,7 @@ extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) { return
 extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse,
                                  void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
                                  dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_MFMA, 10.0 * B * heads * (double)N * Nkv * 64, "dgtd_sra_attn_bwd[B=%d,N=%d,Nkv=%d,h=%d]", B, N, Nkv, heads);
   DGTD_REQUIRE(B > 0 && N > 0 && Nkv > 0 && heads > 0, "sra_attn_bwd: bad sizes B=%d N=%d Nkv=%d heads=%d", B, N, Nkv, heads);
   DGTD_REQUIRE(dt == DGTD_F32 || DGTD_IS_HALF(dt), "sra_attn_bwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;

@@ -314,6 +314,7 @@ int pick_qtw(int N, int bh) {
 
 extern "C" int dgtd_sra_attn_fwd(const void* q, const void* kv, void* out, float* lse, int B, int N, int Nkv, int heads,
                                  float scale, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_MFMA, 4.0 * B * heads * (double)N * Nkv * 64, "dgtd_sra_attn_fwd[B=%d,N=%d,Nkv=%d,h=%d]", B, N, Nkv, heads);
   DGTD_REQUIRE(B > 0 && N > 0 && Nkv > 0 && heads > 0, "sra_attn_fwd: bad sizes B=%d N=%d Nkv=%d heads=%d", B, N, Nkv, heads);
   DGTD_REQUIRE(heads <= 65535 && B <= 65535, "sra_attn_fwd: grid limits");
   const int qtw = pick_qtw(N, B * heads);

@@ -21,6 +21,24 @@ void dgtd_set_error(const char* fmt, ...);
 #define DGTD_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) DGTD_FAIL(3, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 
+// ---- opt-in per-call device timing (bench.py's roofline leg; off by default: one relaxed atomic load per entry point) -------------
+// DGTD_PROF(stream, bound, amount, "key[%d]", ...) at the top of an extern "C" entry point: when dgtd_profile_enable(1) is on, a HIP
+// event pair on `stream` brackets everything the entry enqueues; `amount` = algorithmic HBM bytes (bound 0) or MFMA flops (bound 1)
+// of the call.  Records are read back with dgtd_profile_dump().  Same key for both host binding layers.
+struct DgtdProfScope {
+  bool on;
+  hipEvent_t a, b;
+  hipStream_t st;
+  int bound;
+  double amount;
+  char key[112];
+  DgtdProfScope(hipStream_t st, int bound, double amount, const char* fmt, ...) __attribute__((format(printf, 5, 6)));
+  ~DgtdProfScope();
+};
+#define DGTD_PROF(st, bound, amount, ...) DgtdProfScope dgtd_prof_scope_((hipStream_t)(st), (bound), (double)(amount), __VA_ARGS__)
+enum { DGTD_HBM = 0, DGTD_MFMA = 1 };
+static inline int dgtd_esize(dgtd_dtype dt) { return (dt == DGTD_BF16 || dt == DGTD_F16) ? 2 : (dt == DGTD_F64 ? 8 : 4); }
+
 // ---- scalar load/store as float for both I/O dtypes ---------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }

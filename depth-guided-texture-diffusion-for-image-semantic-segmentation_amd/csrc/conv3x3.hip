@@ -423,6 +423,7 @@ extern "C" int dgtd_conv3x3_supported(int Ci, int Co, int H, int W) { return sup
 
 extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
                                 int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co), "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad sizes");
   DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_fwd: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
@@ -453,6 +454,7 @@ extern "C" int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int 
 
 extern "C" int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
                                   int H, int W, int Ci, int Co, int shared_x, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci + (double)Z * Co * (mask ? 2 : 1)), "dgtd_conv3x3_wgrad[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_wgrad: bad sizes");
   DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_wgrad: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_wgrad: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);

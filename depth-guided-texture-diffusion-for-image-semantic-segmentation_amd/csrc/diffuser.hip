@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void diffuse_tail_bwd_mix_kernel(const float* 
 
 extern "C" int dgtd_diffuser_fwd(const float* x_hp, const float* depth, const float* reg_w, const float* reg_b,
                                  const float* enc_w, const float* enc_b, float* x4, int B, int S, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * B * (4 * 144 + 24 * 144), "dgtd_diffuser_fwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S >= G, "diffuser_fwd: bad sizes B=%d S=%d", B, S);
   hipLaunchKernelGGL(diffuser_fwd_kernel, dim3(LAT, B), dim3(256), 0, (hipStream_t)s, x_hp, depth, reg_w, reg_b, enc_w, enc_b, x4, S);
   DGTD_CHECK_LAUNCH("diffuser_fwd");
@@ -273,6 +274,7 @@ extern "C" int dgtd_diffuser_fwd(const float* x_hp, const float* depth, const fl
 extern "C" int dgtd_diffuser_bwd(const float* x_hp, const float* depth, const float* reg_w, const float* reg_b,
                                  const float* enc_w, const float* enc_b, const float* g4, float* d_reg_w, float* d_reg_b,
                                  float* d_enc_w, float* d_enc_b, int B, int S, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * B * (4 * 144 + 2 * 24 * 144), "dgtd_diffuser_bwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S >= G, "diffuser_bwd: bad sizes B=%d S=%d", B, S);
   hipLaunchKernelGGL(diffuser_bwd_kernel, dim3(LAT, B), dim3(256), 0, (hipStream_t)s, x_hp, depth, reg_w, reg_b, enc_w, enc_b, g4,
                      d_reg_w, d_reg_b, d_enc_w, d_enc_b, S);
@@ -282,6 +284,7 @@ extern "C" int dgtd_diffuser_bwd(const float* x_hp, const float* depth, const fl
 
 extern "C" int dgtd_diffuse_tail_fwd(const float* x4, const float* cw, const float* cb, const float* image, float* out,
                                      int B, int S, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * 4 * B * 3 * S * S, "dgtd_diffuse_tail_fwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S >= 4 && S % 4 == 0, "diffuse_tail_fwd: S=%d must be a positive multiple of 4", S);
   const int gx = (int)std::min<int64_t>(cdiv((int64_t)S * (S / 4), 256), 256);
   hipLaunchKernelGGL(diffuse_tail_fwd_kernel, dim3(gx, 3 * B), dim3(256), 0, (hipStream_t)s, x4, cw, cb, image, out, S);
@@ -293,6 +296,7 @@ extern "C" int64_t dgtd_diffuse_tail_bwd_workspace(int B) { return (int64_t)B * 
 
 extern "C" int dgtd_diffuse_tail_bwd(const float* gout, const float* x4, const float* cw, float* g4, float* d_cw, float* d_cb,
                                      void* workspace, int B, int S, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * B * 3 * S * S, "dgtd_diffuse_tail_bwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S >= G, "diffuse_tail_bwd: bad sizes B=%d S=%d", B, S);
   float* ge2 = (float*)workspace;
   hipLaunchKernelGGL(diffuse_tail_bwd_cells_kernel, dim3(P, 3 * B), dim3(256), 0, (hipStream_t)s, gout, ge2, S);

@@ -315,6 +315,7 @@ int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* 
 
 extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y, int B, int H, int W,
                                int C, int K, int mode, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (mode >= 2 ? 3.0 : 2.0) * dgtd_esize(dt) * B * H * W * C, "dgtd_dwconv_fwd[k%d,mode%d,%dx%dx%d]", K, mode, H, W, C);
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_fwd: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_fwd: K=%d (only 3 and 7 are on the path)", K);
   DGTD_REQUIRE(mode >= 0 && mode <= 3 && (mode < 2 || aux), "dwconv_fwd: bad mode %d", mode);
@@ -341,6 +342,7 @@ extern "C" int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, 
 
 extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W,
                                       int C, int K, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * B * H * W * C, "dgtd_dwconv_bwd_weight[k%d,%dx%dx%d]", K, H, W, C);
   DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight: bad sizes");
   DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight: K=%d (only 3 and 7 are on the path)", K);
   hipStream_t st = (hipStream_t)s;

@@ -265,6 +265,7 @@ int colsum2_launch(const void* g, const void* y, const float* s, const float* ga
 
 extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out, int64_t rows,
                                        int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_PROF(st, DGTD_HBM, 3.0 * dgtd_esize(dt) * rows * C, "dgtd_scale_residual_fwd[rows=%lld,C=%d]", (long long)rows, C);
   DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0, "scale_residual_fwd: bad sizes");
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(C % V == 0, "scale_residual_fwd: C=%d must be a multiple of %d", C, V);
@@ -281,6 +282,7 @@ extern "C" int64_t dgtd_colsum_workspace(int C) { return (int64_t)EW_MAX_BLOCKS 
 
 extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
                                        void* workspace, int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_PROF(st, DGTD_HBM, (gamma ? 3.0 : 2.0) * dgtd_esize(dt) * rows * C, "dgtd_scale_residual_bwd[rows=%lld,C=%d]", (long long)rows, C);
   DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0, "scale_residual_bwd: bad sizes");
   DGTD_REQUIRE((gamma == nullptr) == (dgamma == nullptr), "scale_residual_bwd: gamma and dgamma go together");
   hipStream_t h = (hipStream_t)st;
@@ -294,6 +296,7 @@ extern "C" int dgtd_scale_residual_bwd(const void* g, const void* y, const float
 }
 
 extern "C" int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_PROF(st, DGTD_HBM, 1.0 * dgtd_esize(dt) * rows * C, "dgtd_colsum[rows=%lld,C=%d]", (long long)rows, C);
   DGTD_REQUIRE(rows > 0 && C > 0, "colsum: bad sizes");
   DGTD_REQUIRE(out_dt == DGTD_F32 || DGTD_IS_HALF(out_dt), "colsum: bad output dtype %d", (int)out_dt);
   const int ob = (int)out_dt;
@@ -308,6 +311,7 @@ extern "C" int64_t dgtd_colsum2_workspace(int C) { return (int64_t)EW_MAX_BLOCKS
 extern "C" int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* dgamma,
                                             void* dbias, dgtd_dtype bias_dt, void* workspace, int64_t rows, int C,
                                             int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_PROF(st, DGTD_HBM, (gamma ? 3.0 : 2.0) * dgtd_esize(dt) * rows * C, "dgtd_scale_residual_bias_bwd[rows=%lld,C=%d]", (long long)rows, C);
   DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0 && dbias, "scale_residual_bias_bwd: bad sizes");
   DGTD_REQUIRE((gamma == nullptr) == (dgamma == nullptr), "scale_residual_bias_bwd: gamma and dgamma go together");
   DGTD_REQUIRE(bias_dt == DGTD_F32 || DGTD_IS_HALF(bias_dt), "scale_residual_bias_bwd: bad bias dtype %d", (int)bias_dt);
@@ -321,6 +325,7 @@ extern "C" int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const 
 
 extern "C" int dgtd_gelu_bias_bwd(const void* g, const void* pre, void* dpre, void* dbias, dgtd_dtype bias_dt, void* workspace,
                                   int64_t rows, int C, dgtd_dtype dt, dgtd_stream st) {
+  DGTD_PROF(st, DGTD_HBM, 3.0 * dgtd_esize(dt) * rows * C, "dgtd_gelu_bias_bwd[rows=%lld,C=%d]", (long long)rows, C);
   DGTD_REQUIRE(rows > 0 && C > 0 && dbias, "gelu_bias_bwd: bad sizes");
   DGTD_REQUIRE(bias_dt == DGTD_F32 || DGTD_IS_HALF(bias_dt), "gelu_bias_bwd: bad bias dtype %d", (int)bias_dt);
   hipStream_t h = (hipStream_t)st;

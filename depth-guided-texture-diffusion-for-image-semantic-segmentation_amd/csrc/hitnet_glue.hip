@@ -289,6 +289,7 @@ inline int ew_grid(int64_t items) { return (int)std::min<int64_t>(cdiv(items, 25
 }  // namespace
 
 extern "C" int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * n, "dgtd_prelu_fwd[n=%lld]", (long long)n);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_fwd: n=%lld must be a positive multiple of %d", (long long)n, V);
   if (dt == DGTD_F16) hipLaunchKernelGGL(prelu_fwd_kernel<f16_t>, dim3(ew_grid(n / V)), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, a, (f16_t*)y, n);
@@ -300,6 +301,7 @@ extern "C" int dgtd_prelu_fwd(const void* x, const float* a, void* y, int64_t n,
 }
 
 extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void* dx, float* da, int64_t n, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 3.0 * dgtd_esize(dt) * n, "dgtd_prelu_bwd[n=%lld]", (long long)n);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(n > 0 && n % V == 0, "prelu_bwd: n=%lld must be a positive multiple of %d", (long long)n, V);
   const int grid = std::min(ew_grid(n / V), 512);
@@ -314,6 +316,7 @@ extern "C" int dgtd_prelu_bwd(const void* x, const void* g, const float* a, void
 // stats fp32 [B*C (pooled sums) | B*C (gate) | B*R (hidden) | 64*B*C (per-slice partial sums)]: nothing to zero
 extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const float* w2, void* out, float* stats, int B, int HW,
                                 int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 3.0 * dgtd_esize(dt) * B * HW * C, "dgtd_ca_gate_fwd[B=%d,HW=%d,C=%d]", B, HW, C);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_fwd: unsupported sizes C=%d R=%d", C, R);
   DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
@@ -337,6 +340,7 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
 // scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums) | B*2*R*C (per-sample dw)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero
 extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                                 float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 3.0 * dgtd_esize(dt) * B * HW * C, "dgtd_ca_gate_bwd[B=%d,HW=%d,C=%d]", B, HW, C);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_bwd: unsupported sizes C=%d R=%d", C, R);
   DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "ca_gate_bwd: bad dtype %d", (int)dt);
@@ -360,6 +364,7 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
 
 extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
                                  dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 1.0 * dgtd_esize(dt) * B * C * ((double)Hi * Wi + (double)Ho * Wo), "dgtd_bilinear_fwd[%dx%d->%dx%d,C=%d]", Hi, Wi, Ho, Wo, C);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_fwd: bad sizes (C=%d must be a multiple of %d)", C, V);
   const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);
@@ -374,6 +379,7 @@ extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, 
 
 extern "C" int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,
                                  dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 1.0 * dgtd_esize(dt) * B * C * ((double)Hi * Wi + (double)Ho * Wo), "dgtd_bilinear_bwd[%dx%d<-%dx%d,C=%d]", Hi, Wi, Ho, Wo, C);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "bilinear_bwd: bad sizes (C=%d must be a multiple of %d)", C, V);
   const Axis ah = make_axis(Hi, Ho, align_corners), aw = make_axis(Wi, Wo, align_corners);

@@ -288,6 +288,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
 
 extern "C" int dgtd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                   int64_t rows, int C, float eps, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * rows * C, "dgtd_layernorm_fwd[rows=%lld,C=%d]", (long long)rows, C);
   if (dt == DGTD_F32) return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   if (dt == DGTD_BF16) return ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
   if (dt == DGTD_F16) return ln_fwd_launch<f16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)s);
@@ -297,6 +298,7 @@ extern "C" int dgtd_layernorm_fwd(const void* x, const float* gamma, const float
 extern "C" int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                       const void* dx_add, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
                                       dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (dx_add ? 4.0 : 3.0) * dgtd_esize(dt) * rows * C, "dgtd_layernorm_bwd[rows=%lld,C=%d]", (long long)rows, C);
   if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
@@ -308,6 +310,7 @@ extern "C" int64_t dgtd_layernorm_bwd_workspace(int C) { return (int64_t)LN_BWD_
 extern "C" int dgtd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
                                   dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 3.0 * dgtd_esize(dt) * rows * C, "dgtd_layernorm_bwd[rows=%lld,C=%d]", (long long)rows, C);
   if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);
   if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);
   if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s);

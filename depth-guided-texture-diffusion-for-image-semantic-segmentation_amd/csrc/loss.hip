@@ -173,6 +173,7 @@ extern "C" int64_t dgtd_seg_loss_workspace(int B, int S) { return ((int64_t)B * 
 // workspace layout: weit [B,S,S] | sums [5,B,3] | wsum [B]   (kept by the caller between fwd and bwd)
 extern "C" int dgtd_seg_loss_fwd(const float* lo, const float* label, const float* mix, float* loss, void* workspace, int B, int S,
                                  int hs, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * B * S * S * 4, "dgtd_seg_loss_fwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S > 0 && hs > 0, "seg_loss_fwd: bad sizes B=%d S=%d hs=%d", B, S, hs);
   hipStream_t st = (hipStream_t)s;
   float* weit = (float*)workspace;
@@ -193,6 +194,7 @@ extern "C" int dgtd_seg_loss_fwd(const float* lo, const float* label, const floa
 
 extern "C" int dgtd_seg_loss_bwd(const float* lo, const float* label, const float* mix, const float* gout, float* dlo,
                                  const void* workspace, int B, int S, int hs, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 4.0 * B * S * S * 2 * 4, "dgtd_seg_loss_bwd[B=%d,S=%d]", B, S);
   DGTD_REQUIRE(B > 0 && S > 0 && hs > 0, "seg_loss_bwd: bad sizes B=%d S=%d hs=%d", B, S, hs);
   const float* weit = (const float*)workspace;
   const float* sums = weit + (size_t)B * S * S;

@@ -129,6 +129,7 @@ bool check_sizes(int N, int S, int M, int D, int L, int Lq, int P) { return N > 
 extern "C" int dgtd_ms_deform_attn_fwd(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                        const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M, int D, int L,
                                        int Lq, int P, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (double)dgtd_esize(dt) * N * Lq * M * D * (4.0 * L * P + 1), "dgtd_ms_deform_attn_fwd[N=%d,Lq=%d,M=%d,D=%d,L=%d,P=%d]", N, Lq, M, D, L, P);
   DGTD_REQUIRE(check_sizes(N, S, M, D, L, Lq, P), "ms_deform_attn_fwd: bad sizes");
   const int64_t total = (int64_t)N * Lq * M * D;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 65536));
@@ -143,6 +144,7 @@ extern "C" int dgtd_ms_deform_attn_bwd(const void* value, const int64_t* spatial
                                        const void* sampling_loc, const void* attn_weight, const void* grad_out, void* grad_value,
                                        void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                                        dgtd_dtype dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (double)dgtd_esize(dt) * N * Lq * M * D * (8.0 * L * P + 1), "dgtd_ms_deform_attn_bwd[N=%d,Lq=%d,M=%d,D=%d,L=%d,P=%d]", N, Lq, M, D, L, P);
   DGTD_REQUIRE(check_sizes(N, S, M, D, L, Lq, P), "ms_deform_attn_bwd: bad sizes");
   const int64_t blocks = (int64_t)N * Lq * M;
   DGTD_REQUIRE(blocks < (1LL << 31), "ms_deform_attn_bwd: too many (n, q, m) triples");

@@ -111,6 +111,7 @@ extern "C" int64_t dgtd_preprocess_workspace(int Hin, int Win, int C, int S) {
 
 extern "C" int dgtd_preprocess(const void* img_u8, void* out, const float* mean_host, const float* std_host, void* workspace, int Hin,
                                int Win, int C, int S, int flip, dgtd_dtype out_dt, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (double)Hin * Win * C + (double)dgtd_esize(out_dt) * C * S * S, "dgtd_preprocess[%dx%dx%d->%d]", Hin, Win, C, S);
   DGTD_REQUIRE(Hin > 0 && Win > 0 && S > 0 && C >= 1 && C <= 4, "preprocess: bad sizes H=%d W=%d C=%d S=%d", Hin, Win, C, S);
   DGTD_REQUIRE((mean_host == nullptr) == (std_host == nullptr), "preprocess: mean and std go together");
   DGTD_REQUIRE(out_dt == DGTD_F32 || DGTD_IS_HALF(out_dt), "preprocess: bad output dtype %d", (int)out_dt);

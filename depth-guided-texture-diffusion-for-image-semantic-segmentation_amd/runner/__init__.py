@@ -4,3 +4,4 @@ from .data import DefaultSampler, SyntheticRGBD, batches, device_preprocess, dev
 from . import metrics  # noqa: F401  # noqa: F401
 from .checkpoint import load_checkpoint, load_checkpoint_file, load_pretrained, save_checkpoint  # noqa: F401
 from .config import CosineByEpoch, Runner, build_model, build_optim, load_config  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401

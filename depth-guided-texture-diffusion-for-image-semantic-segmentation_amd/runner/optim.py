@@ -82,7 +82,7 @@ class FlatAdamW:
     logical shapes, ``param_groups`` with parameter indices, plus ``param_names``), whatever the bucket size was."""
 
     def __init__(self, reducer, lr: float = 5e-4, weight_decay: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8,
-                 custom_keys: Optional[Dict[str, float]] = None, scaler: Optional[LossScaler] = None):
+                 custom_keys: Optional[Dict[str, float]] = None, scaler: Optional[LossScaler] = None, graph_safe: bool = False):
         from .. import _lib as L
         self._L = L
         self.reducer, self.scaler = reducer, scaler
@@ -102,11 +102,28 @@ class FlatAdamW:
             self.state.append({"exp_avg": torch.zeros_like(b["mflat"]), "exp_avg_sq": torch.zeros_like(b["mflat"])})
         wd = reducer.working_dtype
         self._w_dt = L.F16 if wd == torch.float16 else L.BF16
+        # graph_safe: no per-step HOST value may enter a launch (a captured hipGraph would replay it frozen): the step count for the
+        # bias corrections and the learning rates live in device memory.  Without a loss scaler the same device state is used with
+        # scale = 1 and growth/backoff = 1, so only its step counter moves.
+        self.graph_safe = graph_safe
+        dev = reducer.buckets[0]["mflat"].device if reducer.buckets else "cpu"
+        self._state = scaler.state if scaler is not None else (
+            torch.tensor([1.0, 0.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=dev) if graph_safe else None)
+        self._lr_dev = torch.tensor([g["lr"] for g in self.param_groups], dtype=torch.float32, device=dev) if graph_safe else None
+        self._lr_host = [g["lr"] for g in self.param_groups]
 
     @property
     def steps(self) -> int:
         """Optimizer steps actually taken (fp16 mode: read from the scaler's device state - steps it skipped do not count)."""
-        return int(self.scaler.state[4].item()) if self.scaler is not None else self._steps
+        return int(self._state[4].item()) if self._state is not None else self._steps
+
+    def sync_lr(self) -> None:
+        """graph_safe: push the param_groups' learning rates (what a scheduler writes) to device memory; a no-op while unchanged."""
+        if self._lr_dev is not None:
+            cur = [float(g["lr"]) for g in self.param_groups]
+            if cur != self._lr_host:
+                self._lr_dev.copy_(torch.tensor(cur, dtype=torch.float32))
+                self._lr_host = cur
 
     @staticmethod
     def _merge(slots, n_work, missing):
@@ -133,11 +150,11 @@ class FlatAdamW:
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** self._steps, 1.0 - b2 ** self._steps
         st = L.stream_ptr()
-        amp = None
+        amp = self._state.data_ptr() if self._state is not None else None
         if self.scaler is not None:
-            amp = self.scaler.state.data_ptr()
             for b in self.reducer.buckets:          # GradScaler.unscale_'s found_inf over every (already all-reduced) gradient
                 L.call("dgtd_found_inf", b["flat"].data_ptr(), b["flat"].numel(), amp + 12, st)
+        lrp = self._lr_dev.data_ptr() if self._lr_dev is not None else None
         for b, slots, runs, state in zip(self.reducer.buckets, self.slots, self.runs, self.state):
             p, g, m, v, w, nw = b["mflat"], b["flat"], state["exp_avg"], state["exp_avg_sq"], b["wflat"], b["n_work"]
             if b["missing"]:                        # parameters without a gradient this step are skipped, like torch.optim.AdamW does
@@ -146,10 +163,13 @@ class FlatAdamW:
                 wp = (w.data_ptr() + 2 * lo) if (w is not None and hi <= nw) else None
                 L.call("dgtd_adamw_flat_amp", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, wp,
                        self._w_dt, hi - lo, float(self.param_groups[gi]["lr"]), b1, b2, self.eps,
-                       float(self.param_groups[gi]["weight_decay"]), bc1, bc2, amp, st)
+                       float(self.param_groups[gi]["weight_decay"]), bc1, bc2, amp,
+                       (lrp + 4 * gi) if lrp is not None else None, st)
         if self.scaler is not None:
             L.call("dgtd_loss_scale_update", self.scaler.state.data_ptr(), float(self.scaler.growth_factor),
                    float(self.scaler.backoff_factor), int(self.scaler.growth_interval), st)
+        elif self._state is not None:               # only the device-side step counter moves
+            L.call("dgtd_loss_scale_update", amp, 1.0, 1.0, 1 << 30, st)
 
     # ------------------------------------------------------------------ torch.optim.AdamW-compatible state
     def _logical(self, b, i, flat):
@@ -194,8 +214,8 @@ class FlatAdamW:
                 self._logical(b, i, st["exp_avg_sq"]).copy_(src["exp_avg_sq"])
                 steps = int(float(src["step"])) if steps is None else steps
         self._steps = steps or 0
-        if self.scaler is not None:
-            self.scaler.state[4] = float(self._steps)
+        if self._state is not None:
+            self._state[4] = float(self._steps)
         by_mult = sorted(sd["param_groups"], key=lambda g: -g["initial_lr"])
         for g, src in zip(self.param_groups, by_mult):
             g["lr"], g["initial_lr"], g["weight_decay"] = src["lr"], src["initial_lr"], src["weight_decay"]

@@ -34,6 +34,14 @@ typedef void* dgtd_stream; /* hipStream_t */
 int dgtd_version(void);
 const char* dgtd_last_error(void);
 
+/* ---- opt-in per-call device timing (measurement only; bench.py's roofline leg) ---------------------------------------------
+ * enable(1) clears earlier records and makes every entry point below bracket what it enqueues with a HIP event pair on the caller's
+ * stream, tagged with a key (entry name + shape) and the call's algorithmic HBM bytes or MFMA flops; enable(0) stops
+ * recording.  dump() waits for the events and writes one line per call: "key<TAB>hbm|mfma<TAB>amount<TAB>milliseconds"; it returns
+ * the buffer size the full text needs.  The only mutable global state of the library, behind a mutex, inert unless enabled.      */
+int dgtd_profile_enable(int on);
+int64_t dgtd_profile_dump(char* buf, int64_t cap);
+
 /* ---- LayerNorm over the last dim of a [rows, C] token matrix ---------------------------------
  * replaces nn.LayerNorm / F.layer_norm at twig/model/cod.py:979,881,929,936,1367-1391,1043.
  * gamma/beta fp32 [C].  mean/rstd fp32 [rows] are written for the backward.                    */
@@ -202,10 +210,12 @@ int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, 
  * config/sod.yml:57) folded in.  amp_state (device, fp32 [5] = { scale, growth_tracker, 1/scale, found_inf, steps taken }, or NULL):
  * gradients are multiplied by 1/scale, the whole launch is a no-op when found_inf != 0 (GradScaler.unscale_ + the skipped step of
  * an overflowed iteration) and the bias corrections are 1 - beta^(steps taken + 1) computed on the device (skipped steps do not
- * count; bias_correction1/2 are ignored).                                                                                        */
+ * count; bias_correction1/2 are ignored).  lr_dev (device scalar or NULL): when given, the learning rate is read from it instead of
+ * `lr` - together with amp_state this leaves no per-step host value in the launch, so a captured hipGraph of the step replays
+ * correctly while the schedule and the step count advance.                                                                        */
 int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                        const float* amp_state, dgtd_stream s);
+                        const float* amp_state, const float* lr_dev, dgtd_stream s);
 /* found[0] = 1 when g[0,n) (fp32, the still scaled gradients) holds an inf or a NaN; untouched otherwise.                        */
 int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s);
 /* GradScaler.update() on the device: state fp32 [5] (layout above); found_inf != 0: scale *= backoff, tracker = 0; else steps += 1,

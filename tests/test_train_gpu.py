@@ -265,3 +265,59 @@ def test_fp16_training_tracks_bf16_loss_curve(dgtd, S, B):
     assert abs(l16[0] - lbf[0]) < 0.02 * abs(lbf[0]), (l16[0], lbf[0])         # same weights, same batch: only the arithmetic differs
     m16, mbf = sum(l16[-4:]) / 4, sum(lbf[-4:]) / 4                           # fp16 lags by the few steps its scaler skipped
     assert abs(m16 - mbf) < 0.10 * abs(mbf), (l16, lbf)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=str)
+def test_graphed_step_matches_eager(dgtd, dtype):
+    """the whole training step (forward + loss + backward + bucket gather + AdamW) captured as ONE hipGraph and
+    replayed must follow the eager step: same losses and weights over 3 steps after the same warm-up (fp32: to fp32-atomic noise;
+    bf16: finite and close), with the learning rate changed between replays (device-resident lr) and the optimizer's step count
+    advancing on the device."""
+    S, B, W = 64, 2, 2
+    data = dgtd.runner.SyntheticRGBD(S, B, device="cuda")
+    batches = [data.batch_at(i) for i in range(3)]
+
+    def make():
+        torch.manual_seed(0)
+        net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=dtype)
+        filler.fill_module(net)
+        net = net.cuda().train()
+        red = dgtd.dist.GradReducer(net, working_dtype=dtype)
+        opt = dgtd.runner.FlatAdamW(red, lr=1e-4, graph_safe=True)
+        return net, red, opt
+
+    def eager_step(net, red, opt, b):
+        red.zero_grad()
+        loss = net(b["raw"], b["input"], b["label"], b["depth"], mode="loss")["loss"]
+        loss.backward()
+        red.finish()
+        opt.sync_lr()
+        opt.step()
+        return loss.item()
+
+    net_e, red_e, opt_e = make()
+    for _ in range(W):
+        eager_step(net_e, red_e, opt_e, batches[0])
+    want = []
+    for i in range(3):
+        if i == 2:
+            for g in opt_e.param_groups:
+                g["lr"] *= 0.5
+        want.append(eager_step(net_e, red_e, opt_e, batches[i]))
+
+    net_g, red_g, opt_g = make()
+    stepper = dgtd.runner.GraphedTrainStep(net_g, red_g, opt_g, warmup=W)
+    stepper.capture(batches[0])
+    got = []
+    for i in range(3):
+        if i == 2:
+            for g in opt_g.param_groups:
+                g["lr"] *= 0.5
+        got.append(stepper(batches[i]).item())
+    assert opt_g.steps == opt_e.steps == W + 3
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a_, b_ in zip(got, want):
+        assert math.isfinite(a_) and abs(a_ - b_) <= tol * max(1.0, abs(b_)), (got, want)
+    if dtype == torch.float32:
+        for (k, p), (_, q) in zip(net_g.named_parameters(), net_e.named_parameters()):
+            torch.testing.assert_close(p, q, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f"{k}: {m}")
