@@ -53,6 +53,7 @@ SIGNATURES = {
     "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp]),
     "dgtd_found_inf": (_i, [_fp, _i64, _fp, _vp]),
     "dgtd_loss_scale_update": (_i, [_fp, _f, _f, _i, _vp]),
+    "dgtd_multi_copy": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _i, _vp, _i, _i, _vp]),
     "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ms_deform_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_preprocess_workspace": (_i64, [_i, _i, _i, _i]),
@@ -178,3 +179,16 @@ def call(name: str, *args, algo=None, key=None):
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def multi_copy(tensors, offsets, flat: torch.Tensor, to_tensors: bool = False) -> None:
+    """``flat[offsets[i] : offsets[i] + tensors[i].numel()] = tensors[i]`` (or the reverse) for every i in ONE launch per 128
+    tensors, converting between the tensors' dtype and ``flat``'s.  Tensors must be contiguous and share one dtype."""
+    n = len(tensors)
+    if n == 0:
+        return
+    check_cuda(flat, *tensors)
+    tdt = dtype_code(tensors[0])
+    P, I = C.c_void_p * n, C.c_int64 * n
+    call("dgtd_multi_copy", P(*[t.data_ptr() for t in tensors]), I(*[int(o) for o in offsets]), I(*[t.numel() for t in tensors]), n, tdt,
+         flat.data_ptr(), dtype_code(flat), int(to_tensors), stream_ptr())

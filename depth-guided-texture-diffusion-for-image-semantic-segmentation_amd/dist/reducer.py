@@ -255,6 +255,20 @@ class GradReducer:
                     else:
                         gv.copy_(g)
                 return
+            if flat.is_cuda:
+                # ONE launch per 128 tensors and dtype: 16-bit gradient -> fp32 bucket slot directly (no concat + cast), table by value
+                # in the kernel arguments (hipGraph-safe; torch.cat on ROCm is not, csrc/multicopy.hip).  Padding slots are never
+                # written and stay zero.
+                from .. import _lib as L
+                by_dtype = {}
+                for i, (g, c) in enumerate(zip(gs, nhwc[lo:hi])):
+                    v = flat1d(g, c)
+                    by_dtype.setdefault(v.dtype, ([], []))
+                    by_dtype[v.dtype][0].append(v if v.is_contiguous() else v.contiguous())
+                    by_dtype[v.dtype][1].append(bucket["offsets"][lo + i])
+                for ts, offs in by_dtype.values():
+                    L.multi_copy(ts, offs, flat)
+                return
             parts = []
             for i, (g, c) in enumerate(zip(gs, nhwc[lo:hi])):
                 parts.append(flat1d(g, c))

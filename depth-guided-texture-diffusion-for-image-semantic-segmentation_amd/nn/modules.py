@@ -322,7 +322,7 @@ class ShapePropEncoder(nn.Module):
                 taps.append(ops.bilinear_resize(y, size[0], size[1], False))
             else:
                 taps.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
-        cat = torch.cat(taps, dim=1)
+        cat = ops.cat_channels(taps)
         fw, fb = wb(self.fusion_conv)                            # 1x1 conv == GEMM on tokens
         Bc, Cc, Hc, Wc = cat.shape
         return _tokens_to_nchw(ops.linear(_nchw_to_tokens(cat), fw.flatten(1), fb), Hc, Wc) if cat.is_cuda else self.fusion_conv(cat)
@@ -705,12 +705,12 @@ class Hitnet(nn.Module):
         stage_loss, cfm = [], None
         for it in range(4):
             if cfm is not None:
-                x4_t = self.compress_out(torch.cat((_up(x4_t, 4, True), cfm), 1))
+                x4_t = self.compress_out(ops.cat_channels((_up(x4_t, 4, True), cfm)))
             x4f = self.decoder_level4(x4_t)
-            x3f = self.decoder_level3(torch.cat((x3_t, _up(x4f, 2, True)), 1))
+            x3f = self.decoder_level3(ops.cat_channels((x3_t, _up(x4f, 2, True))))
             if it > 0:
-                x2_t = self.compress_out2(torch.cat((x2_t, cfm), 1))
-            x2f = self.decoder_level2(torch.cat((x2_t, _up(x3f, 2, True)), 1))
+                x2_t = self.compress_out2(ops.cat_channels((x2_t, cfm)))
+            x2f = self.decoder_level2(ops.cat_channels((x2_t, _up(x3f, 2, True))))
             cfm = self.conv4(x2f)
             pred = self.out_CFM(cfm).float()
             stage_loss.append(pred if lowres else _up(pred, 8, False))

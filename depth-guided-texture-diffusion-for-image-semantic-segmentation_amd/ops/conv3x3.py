@@ -80,8 +80,9 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
 def conv3x3_stack(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Optional[Sequence[torch.Tensor]], relu: bool) -> torch.Tensor:
     """Z convolutions in one launch.  x: NHWC [B,H,W,Ci] shared by all, or [Z,B,H,W,Ci]; weights: Z Conv2d weights [Co,Ci,3,3].
     Returns NHWC [Z,B,H,W,Co]."""
-    w = torch.stack([_w.permute(0, 2, 3, 1) for _w in weights])
-    b = torch.stack(list(biases)) if biases is not None else None
+    from .hitnet import stack
+    w = stack([_w.permute(0, 2, 3, 1) for _w in weights])        # views for the O,H,W,I storage of the reducer's working copies
+    b = stack(list(biases)) if biases is not None else None
     if x.ndim == 4:
         x = x.unsqueeze(0)
     nat = _native.ops()

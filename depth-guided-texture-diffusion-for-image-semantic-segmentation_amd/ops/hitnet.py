@@ -136,3 +136,62 @@ def bilinear_resize(x: torch.Tensor, out_h: int, out_w: int, align_corners: bool
     if nat is not None and x.is_cuda:
         return nat.bilinear_resize(x, int(out_h), int(out_w), bool(align_corners))
     return _BilinearFn.apply(x, int(out_h), int(out_w), bool(align_corners))
+
+
+class _StackFn(Function):
+    """torch.stack(tensors, 0) for same-shape contiguous tensors as ONE dgtd_multi_copy launch (hipGraph-safe, see csrc/multicopy.hip);
+    the backward hands each input its slice of the gradient (views, no kernel)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [x.contiguous() for x in xs]
+        out = torch.empty((len(xs),) + tuple(xs[0].shape), dtype=xs[0].dtype, device=xs[0].device)
+        n = xs[0].numel()
+        L.multi_copy(xs, [i * n for i in range(len(xs))], out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+def stack(tensors) -> torch.Tensor:
+    tensors = list(tensors)
+    if not tensors[0].is_cuda or any(t.dtype != tensors[0].dtype for t in tensors):
+        return torch.stack(tensors)
+    return _StackFn.apply(*tensors)
+
+
+class _CatChannelsFn(Function):
+    """torch.cat(maps, dim=1) for channels_last maps [B,C_i,H,W] (the skip concatenations of the Hitnet decoder, cod.py:777-792, and
+    the four taps of ShapePropEncoder, cod.py:1176): one strided copy per input into a channels_last output, gradient = channel
+    slices (views).  No torch.cat: see csrc/multicopy.hip on why it cannot be captured in a hipGraph on ROCm."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H, W = xs[0].shape
+        ctx.splits = [x.shape[1] for x in xs]
+        out = torch.empty((B, sum(ctx.splits), H, W), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
+        off = 0
+        for x in xs:
+            out.narrow(1, off, x.shape[1]).copy_(x)
+            off += x.shape[1]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.splits:
+            outs.append(g.narrow(1, off, c))
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(maps) -> torch.Tensor:
+    maps = list(maps)
+    if not maps[0].is_cuda:
+        return torch.cat(maps, dim=1)
+    dt = maps[0].dtype
+    return _CatChannelsFn.apply(*[m if m.dtype == dt else m.to(dt) for m in maps])

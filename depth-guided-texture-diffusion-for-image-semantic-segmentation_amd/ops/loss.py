@@ -50,5 +50,6 @@ class _SegLossFn(Function):
 
 def seg_loss(lowres_maps, label, weights=(0.0, 0.2, 0.4, 0.6, 1.0)):
     """lowres_maps: five [B,1,hs,hs] tensors (P1[0..3] and P2 before their x8 up-sampling)."""
-    lo = torch.stack([m.float().squeeze(1) for m in lowres_maps]).contiguous()
+    from .hitnet import stack
+    lo = stack([m.float().squeeze(1) for m in lowres_maps])
     return _SegLossFn.apply(lo, label.float().contiguous(), _mix(weights, lo.device))

@@ -13,6 +13,8 @@ call.  What had to be true for capture to be correct (the round-1 attempt crashe
   capture, and gradients are ``None`` when capture starts (backward then allocates them from the graph's private pool);
 * the gradient reducer does not mutate ``.grad`` from inside autograd hooks under capture (world 1: hooks only count; the gather runs
   once after backward, inside the capture);
+* no torch.cat / torch.stack in the captured region (see ``_no_cat``): that, not the autograd engine, was what made the round-1
+  replays produce NaNs;
 * world > 1: the all-reduce stays OUTSIDE the graphs (graph A = forward/backward/gather, eager bucketed all-reduce, graph B = AdamW).
 """
 from __future__ import annotations
@@ -20,6 +22,26 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+
+
+class _no_cat:
+    """torch.cat / torch.stack must not run inside the captured region: on ROCm their tensor table is staged through a pinned host
+    buffer + H2D copy; a replay re-reads that host buffer after the host allocator has recycled it for some later cat, and gathers
+    from stale pointers (observed: correct replays until the first eager torch.stack after a host synchronisation, then garbage
+    gradients and NaNs; tools/debug_graph_nan.py).  The training path uses dgtd_multi_copy / strided copies instead
+    (ops.stack, ops.cat_channels, the reducer's gather); this guard turns a regression into an error at capture time."""
+
+    def __enter__(self):
+        self._saved = (torch.cat, torch.stack)
+
+        def refuse(*a, **k):
+            raise RuntimeError("torch.cat / torch.stack inside hipGraph capture: not replay-safe on ROCm (runner/graph.py)")
+        torch.cat = torch.stack = refuse
+        return self
+
+    def __exit__(self, *exc):
+        torch.cat, torch.stack = self._saved
+        return False
 
 
 class GraphedTrainStep:
@@ -40,7 +62,11 @@ class GraphedTrainStep:
         s = self.static
         for k in ("input", "label", "depth"):
             v = batch[k]
-            s[k].copy_(torch.stack(list(v)) if isinstance(v, (list, tuple)) else v, non_blocking=True)
+            if isinstance(v, (list, tuple)):                 # mmengine's pseudo_collate: a list of per-sample tensors
+                for i, t in enumerate(v):
+                    s[k][i].copy_(t, non_blocking=True)
+            else:
+                s[k].copy_(v, non_blocking=True)
         s["x_hp"].copy_(self.net.high_pass(s["input"]))
 
     def _fwd_bwd(self):
@@ -89,7 +115,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb, stream=s):
+        with _no_cat(), torch.cuda.graph(self.graph_fb, stream=s):
             self.loss = self._fwd_bwd()
             self._gather_all()
             if not self.split:

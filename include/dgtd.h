@@ -223,6 +223,16 @@ int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s);
  * No host synchronisation anywhere in the scaled step.                                                      */
 int dgtd_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, dgtd_stream s);
 
+/* ---- Many small tensors <-> one flat buffer, with dtype conversion, one launch per 128 tensors ---------------------------------
+ * replaces torch.cat / torch.stack on the training path: the gradient-bucket gather of the data-parallel reducer (what DDP's bucket
+ * copies do for config/sod.yml's MMDistributedDataParallel), the per-step stack of the 16 prompt-decoder kernels and of the five
+ * deep-supervision maps.  tensors / offsets / counts are HOST arrays of n_tensors entries: device pointer of tensor i (contiguous,
+ * dtype tensor_dt), its element offset in `flat` (dtype flat_dt) and its element count.  to_tensors = 0: flat[offset_i + k] =
+ * tensor_i[k];  to_tensors = 1: tensor_i[k] = flat[offset_i + k].  The table travels by value in the kernel arguments, so the launch
+ * can be captured in a hipGraph (torch.cat on ROCm stages its table through recycled pinned host memory and cannot).               */
+int dgtd_multi_copy(const void* const* tensors, const int64_t* offsets, const int64_t* counts, int n_tensors, dgtd_dtype tensor_dt,
+                    void* flat, dgtd_dtype flat_dt, int to_tensors, dgtd_stream s);
+
 /* ---- Multi-scale deformable attention sampling: the reference's own native op (twig/ops) ------------------------
  * replaces MSDA.ms_deform_attn_forward / ms_deform_attn_backward (twig/ops/src/ms_deform_attn.h:20-60, bound at
  * twig/ops/functions/ms_deform_attn_func.py:24-46); semantics = ms_deform_attn_core_pytorch (ms_deform_attn_func.py:49-71).

@@ -517,3 +517,44 @@ def test_prompt_tail_weight_gradient_with_channels_last_weights(dgtd, scale, hal
     torch.testing.assert_close(y.float(), ref.flatten(2).transpose(1, 2), atol=2e-5 if half == torch.float32 else 3e-2, rtol=3e-2)
     rel = float((g.float() - gw_ref).norm() / gw_ref.norm())
     assert rel < (1e-4 if half == torch.float32 else 1e-2), rel
+
+
+# ---------------------------------------------------------------------------------------------- cat / stack replacements
+@pytest.mark.parametrize("src,dst", [(torch.bfloat16, torch.float32), (torch.float16, torch.float32), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float16)], ids=str)
+def test_multi_copy_gathers_and_scatters(dgtd, src, dst):
+    """dgtd_multi_copy: 300 tensors of ragged sizes (odd lengths, unaligned slots, one empty) into one flat buffer with conversion,
+    bit-exact against per-tensor copy_, more than one 128-entry table per call; and back (to_tensors)."""
+    g = torch.Generator().manual_seed(0)
+    sizes = [int(v) for v in torch.randint(1, 5000, (300,), generator=g)] + [0, 8, 2048, 2049, 100003]
+    ts = [_rand(n, seed=i, dtype=src) for i, n in enumerate(sizes)]
+    offs, off = [], 3
+    for n in sizes:
+        offs.append(off)
+        off += n + (n % 5)                    # gaps: slots are neither contiguous nor aligned
+    flat = torch.full((off + 7,), -7.0, device="cuda", dtype=dst)
+    want = flat.clone()
+    for t, o in zip(ts, offs):
+        want[o:o + t.numel()].copy_(t)
+    dgtd._lib.multi_copy(ts, offs, flat)
+    assert torch.equal(flat, want)            # including the untouched gaps
+    back = [torch.zeros_like(t) for t in ts]
+    dgtd._lib.multi_copy(back, offs, flat, to_tensors=True)
+    for t, b in zip(ts, back):
+        assert torch.equal(b, t.to(dst).to(src))
+
+
+def test_stack_and_cat_channels_match_torch(dgtd):
+    xs = [_rand(6, 3, 3, 24, seed=i, dtype=torch.bfloat16).requires_grad_() for i in range(16)]
+    g = _rand(16, 6, 3, 3, 24, seed=99, dtype=torch.bfloat16)
+    y = dgtd.ops.stack(xs)
+    assert torch.equal(y, torch.stack([x.detach() for x in xs]))
+    grads = torch.autograd.grad(y, xs, g)
+    assert all(torch.equal(a, g[i]) for i, a in enumerate(grads))
+    maps = [_rand(2, c, 12, 20, seed=c, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_() for c in (32, 64, 24)]
+    out = dgtd.ops.cat_channels(maps)
+    ref = torch.cat([m.detach() for m in maps], dim=1)
+    assert torch.equal(out, ref) and out.is_contiguous(memory_format=torch.channels_last)
+    go = _rand(*ref.shape, seed=5, dtype=torch.bfloat16)
+    gs = torch.autograd.grad(out, maps, go)
+    assert torch.equal(gs[1], go[:, 32:96]) and torch.equal(gs[2], go[:, 96:])
