@@ -102,7 +102,7 @@ extern "C" int dgtd_multi_copy(const void* const* tensors, const int64_t* offset
   if (n_tensors == 0) return 0;
   double total = 0;
   for (int i = 0; i < n_tensors; ++i) {
-    DGTD_REQUIRE(tensors[i] && counts[i] >= 0 && offsets[i] >= 0, "multi_copy: bad entry %d", i);
+    DGTD_REQUIRE((tensors[i] || counts[i] == 0) && counts[i] >= 0 && offsets[i] >= 0, "multi_copy: bad entry %d", i);
     total += (double)counts[i];
   }
   DGTD_PROF(s, DGTD_HBM, total * (dgtd_esize(tensor_dt) + dgtd_esize(flat_dt)), "dgtd_multi_copy[n=%d,elems=%.0f]", n_tensors, total);

@@ -183,6 +183,9 @@ def gen_model(S: int, B: int, with_grads: bool) -> dict:
         net64 = ref_loader.build_reference_model(S, train=True)
         filler.fill_module(net64)
         net64 = net64.double()
+        # Hitnet's default argument `act=nn.PReLU()` (cod.py:686) is ONE module shared by every Hitnet of the process: the fp32 model
+        # above has already left its gradient on that shared parameter, and backward() accumulates
+        net64.zero_grad(set_to_none=True)
         loss64 = net64(None, x.double(), l.double(), list(d.double()), mode="loss")["loss"]
         loss64.backward()
         out["train.loss64"] = np.float64(loss64.item())
@@ -214,6 +217,7 @@ def gen_grads_fp64(S: int = 64, B: int = 2) -> dict:
         net = ref_loader.build_reference_model(S, train=True)
         filler.fill_module(net)
         net = net.to(dt)
+        net.zero_grad(set_to_none=True)        # the shared default-argument PReLU keeps gradients across model instances
         loss = net(None, x.to(dt), l.to(dt), list(d.to(dt)), mode="loss")["loss"]
         loss.backward()
         out[f"loss.{tag}"] = np.float64(loss.item())

@@ -322,7 +322,7 @@ def test_graphed_step_matches_eager(dgtd, dtype):
         torch.cuda.synchronize()
         del junk
     assert opt_g.steps == opt_e.steps == W + 3
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-4 if dtype == torch.float32 else 2e-2      # fp32: atomic summation order in a few backward kernels
     for a_, b_ in zip(got, want):
         assert math.isfinite(a_) and abs(a_ - b_) <= tol * max(1.0, abs(b_)), (got, want)
     if dtype == torch.float32:
