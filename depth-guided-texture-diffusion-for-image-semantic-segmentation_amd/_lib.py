@@ -53,6 +53,8 @@ SIGNATURES = {
     "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp]),
     "dgtd_found_inf": (_i, [_fp, _i64, _fp, _vp]),
     "dgtd_loss_scale_update": (_i, [_fp, _f, _f, _i, _vp]),
+    "dgtd_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_multi_copy": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _i, _vp, _i, _i, _vp]),
     "dgtd_ms_deform_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ms_deform_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -66,6 +66,10 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         w, b = wb(self)
+        if (x.is_cuda and _USE["conv_gemm"] and self.groups == 1 and self.dilation == (1, 1) and self.kernel_size[0] == self.kernel_size[1]
+                and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and isinstance(self.padding[0], int)
+                and self.padding_mode == "zeros"):
+            return ops.conv2d_gemm(x, w, b, self.stride[0], self.padding[0])      # patch gather + library GEMM, no MIOpen
         return self._conv_forward(x, w, b)
 
 
@@ -149,6 +153,11 @@ class OverlapPatchEmbed(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x):
+        if x.is_cuda and _USE["conv_gemm"]:
+            # patch gather straight from the producer's layout (NCHW fp32 image or channels_last map; the 16-bit cast of the image
+            # happens inside the gather) + one GEMM: the result already is the token matrix
+            t, H, W = ops.conv2d_tokens(x, *wb(self.proj), self.stride, self.patch_size // 2)
+            return self.norm(t), H, W
         x = self.proj(x.contiguous(memory_format=torch.channels_last))   # no-op when the producer already is channels_last
         H, W = x.shape[-2:]
         return self.norm(_nchw_to_tokens(x)), H, W
@@ -425,11 +434,19 @@ class ShapePropDecoder(nn.Module):
         if s_ == 1:
             if _USE["conv3x3"] and w.dtype == h.dtype and ops.conv3x3_ops.supported(h, w.shape[1], w.shape[0], Hin, h.shape[-1]):
                 y = ops.conv3x3(h, w, b)                # stage-1 prompts (24 -> 64 at S/4): same kernel as the trunk layers
+            elif h.is_cuda and _USE["conv_gemm"]:
+                return ops.conv2d_tokens(h, w, b, 1, 1)[0]
             else:
                 y = F.conv2d(h, w, b, padding=1)
         elif s_ in (2, 4, 8) and Hin == H * s_ and h.shape[-1] == W * s_:
             w4 = _fold_2x2_mean(w)                 # mean of the four shifted 3x3 kernels (zero padded), one launch
             off = s_ // 2 - 2                      # first input row/col of the 4x4 window of output 0
+            if h.is_cuda and _USE["conv_gemm"]:
+                # the offset window grid is a strided view the patch gather reads directly (s_ = 4: the windows tile the map)
+                src, pad = (h, -off) if off < 0 else (h[:, :, off:, off:], 0)
+                t, Ht, Wt = ops.conv2d_tokens(src, w4, b, s_, pad)
+                assert (Ht, Wt) == (H, W)
+                return t
             if off < 0:
                 y = F.conv2d(h, w4, b, stride=s_, padding=-off)
             else:

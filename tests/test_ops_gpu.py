@@ -558,3 +558,51 @@ def test_stack_and_cat_channels_match_torch(dgtd):
     go = _rand(*ref.shape, seed=5, dtype=torch.bfloat16)
     gs = torch.autograd.grad(out, maps, go)
     assert torch.equal(gs[1], go[:, 32:96]) and torch.equal(gs[2], go[:, 96:])
+
+
+# ---------------------------------------------------------------------------------------------- dense conv = patch gather + GEMM
+CONV_CASES = [  # (B, Ci, H, W, Co, K, stride, pad, layout)
+    (2, 3, 64, 64, 64, 7, 4, 3, "nchw"),          # patch_embed1 on the fp32 NCHW image
+    (2, 64, 32, 32, 128, 3, 2, 1, "nhwc"),        # patch_embed2..4
+    (2, 24, 32, 32, 40, 4, 2, 1, "nhwc"),         # folded prompt tail, stage 2 (padding 1)
+    (2, 24, 32, 32, 40, 4, 4, 0, "nhwc"),         # stage 3: windows tile the map
+    (2, 24, 30, 30, 40, 4, 8, 0, "offset"),       # stage 4: offset view h[:, :, 2:, 2:]
+    (2, 64, 16, 16, 32, 8, 4, 2, "nhwc"),         # Hitnet.compress_out
+    (2, 32, 12, 20, 1, 1, 1, 0, "nhwc"),          # 1-channel head
+    (1, 96, 24, 24, 96, 3, 1, 1, "nhwc"),         # fp32-mode CAB conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"ci{c[1]}_k{c[5]}s{c[6]}p{c[7]}_{c[8]}" for c in CONV_CASES])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+def test_conv2d_gemm_matches_conv2d(dgtd, case, dtype):
+    """ops.conv2d_gemm (dgtd_im2col + library GEMM, dgtd_col2im in the backward) against F.conv2d in fp32: value, input gradient,
+    weight and bias gradients, for every geometry the model uses, with the weight stored O,H,W,I like the reducer stores it."""
+    B, Ci, H, W, Co, K, S, P, layout = case
+    full = _rand(B, Ci, H + (2 if layout == "offset" else 0), W + (2 if layout == "offset" else 0), seed=1, dtype=torch.float32 if layout == "nchw" else dtype)
+    if layout != "nchw":
+        full = full.contiguous(memory_format=torch.channels_last)
+    full.requires_grad_(layout != "nchw")
+    x = full[:, :, 2:, 2:] if layout == "offset" else full
+    w = (_rand(Co, Ci, K, K, seed=2) / math.sqrt(Ci * K * K)).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = (0.1 * _rand(Co, seed=3)).to(dtype).requires_grad_()
+    xr = x.detach().float().requires_grad_()
+    wr, br = w.detach().float().requires_grad_(), b.detach().float().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=S, padding=P)
+    g = _rand(*ref.shape, seed=4, dtype=dtype)
+    with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+        y = dgtd.ops.conv2d_gemm(x, w, b, S, P)
+    assert y.shape == ref.shape and y.dtype == dtype
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+    ins = ([full] if layout != "nchw" else []) + [w, b]
+    got = torch.autograd.grad(y, ins, g)
+    want = torch.autograd.grad(ref, ([xr] if layout != "nchw" else []) + [wr, br], g.float())
+    if layout != "nchw":
+        gx = got[0][:, :, 2:, 2:] if layout == "offset" else got[0]
+        torch.testing.assert_close(gx.float(), want[0], atol=tol * 4, rtol=tol)
+        if layout == "offset":
+            assert float(got[0][:, :, :2].abs().sum()) == 0.0            # nothing flows into the skipped border
+    n = B * ref.shape[2] * ref.shape[3]
+    assert (got[-2].float() - want[-2]).norm() / want[-2].norm() < (1e-4 if dtype == torch.float32 else 2e-2)
+    torch.testing.assert_close(got[-1].float(), want[-1], atol=tol * math.sqrt(n), rtol=tol)
