@@ -52,22 +52,37 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const T* __restrict__ x,
 template <typename T, bool PRODUCT>
 __global__ __launch_bounds__(256) void pooled_sum_kernel(const T* __restrict__ a, const T* __restrict__ bfac, float* __restrict__ pooled,
                                                          int HW, int C) {
-  __shared__ float red[256];
+  // 16-byte chunks along C (C % V == 0): thread = (row slot, chunk); the row slots of a workgroup meet in LDS
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[256 * 8];
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int cpr = 256 / C > 0 ? 256 / C : 1;          // rows handled per pass (C <= 128 -> at least 2)
-  const int c = tid % C, rl = tid / C;
-  float acc = 0.f;
-  if (rl < cpr) {
-    for (int r = blockIdx.x * cpr + rl; r < HW; r += gridDim.x * cpr) {
-      const size_t o = ((size_t)b * HW + r) * C + c;
-      acc += PRODUCT ? (float)a[o] * (float)bfac[o] : (float)a[o];
+  const int CV = C / V, rpp = 256 / CV;               // rows per pass (C <= 128 -> CV <= 32 -> at least 8)
+  const int cv = tid % CV, rl = tid / CV;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  if (rl < rpp) {
+    const T* ab = a + (size_t)b * HW * C + (size_t)cv * V;
+    const T* bb = PRODUCT ? bfac + (size_t)b * HW * C + (size_t)cv * V : nullptr;
+    for (int r = blockIdx.x * rpp + rl; r < HW; r += gridDim.x * rpp) {
+      const VT v = *reinterpret_cast<const VT*>(ab + (size_t)r * C);
+      if (PRODUCT) {
+        const VT w = *reinterpret_cast<const VT*>(bb + (size_t)r * C);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += (float)v[j] * (float)w[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += (float)v[j];
+      }
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[(rl * CV + cv) * V + j] = acc[j];
   }
-  red[tid] = acc;
   __syncthreads();
   if (tid < C) {
     float s = 0.f;
-    for (int k = 0; k < cpr; ++k) s += red[k * C + tid];
+    for (int k = 0; k < rpp; ++k) s += red[k * C + tid];
     pooled[((size_t)blockIdx.x * gridDim.y + b) * C + tid] = s;
   }
 }
@@ -322,7 +337,7 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
   DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "ca_gate_fwd: bad dtype %d", (int)dt);
   hipStream_t st = (hipStream_t)s;
   float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C, *partial = hidden + (size_t)B * R;
-  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));   // <= 64 slices (the stats / scratch layout), summed per column by the per-sample MLP kernels
   if (dt == DGTD_F16) hipLaunchKernelGGL((pooled_sum_kernel<f16_t, false>), dim3(gx, B), dim3(256), 0, st, (const f16_t*)res, (const f16_t*)nullptr, partial, HW, C);
   else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, partial, HW, C);
@@ -347,7 +362,7 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   hipStream_t st = (hipStream_t)s;
   const float *pooled = stats, *gate = stats + (size_t)B * C, *hidden = gate + (size_t)B * C;
   float *dmean = scratch, *partial = scratch + (size_t)B * C, *dwp = partial + (size_t)64 * B * C;
-  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 16));   // few slices: the per-sample MLP kernels sum them serially
+  const int cpr = std::max(1, 256 / C), gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(HW, cpr * 8), 64));   // <= 64 slices (the stats / scratch layout), summed per column by the per-sample MLP kernels
   if (dt == DGTD_F16) hipLaunchKernelGGL((pooled_sum_kernel<f16_t, true>), dim3(gx, B), dim3(256), 0, st, (const f16_t*)g, (const f16_t*)res, partial, HW, C);
   else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);

@@ -546,7 +546,7 @@ class PyramidVisionTransformerImpr(nn.Module):
     def _prompt_trunks(self, embedding):
         """The two conv3x3(24->24)+ReLU layers of ALL prompt decoders (cod.py:1216-1220; 16 for pvt_v2_b2) as two launches of the
         batched NHWC MFMA kernel: the first reads the shared embedding once per tile, the second maps [Z,B,h,w,24] -> same.
-        Returns NHWC [Z,B,h,w,24], or None when the geometry / dtype is outside the kernel (fp32 parity mode, CPU)."""
+        Returns a tuple of Z NHWC [B,h,w,24] maps, or None when the geometry / dtype is outside the kernel (fp32 parity mode, CPU)."""
         decs = [d for pd in self.prompt_decoder for d in pd.decoder]
         c0, c1 = [d.decoder[0] for d in decs], [d.decoder[2] for d in decs]
         w0 = [wb(c)[0] for c in c0]
@@ -555,7 +555,7 @@ class PyramidVisionTransformerImpr(nn.Module):
             return None
         x = embedding.permute(0, 2, 3, 1).contiguous()
         h = ops.conv3x3_stack(x, w0, [wb(c)[1] for c in c0], True)
-        return ops.conv3x3_stack(h, [wb(c)[0] for c in c1], [wb(c)[1] for c in c1], True)
+        return ops.unstack(ops.conv3x3_stack(h, [wb(c)[0] for c in c1], [wb(c)[1] for c in c1], True))   # Z views, one gather in the backward
 
     def forward(self, x, depth, x_hp=None):
         return self.forward_features(x, depth, x_hp)

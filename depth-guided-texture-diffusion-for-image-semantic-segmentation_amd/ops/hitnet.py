@@ -195,3 +195,32 @@ def cat_channels(maps) -> torch.Tensor:
         return torch.cat(maps, dim=1)
     dt = maps[0].dtype
     return _CatChannelsFn.apply(*[m if m.dtype == dt else m.to(dt) for m in maps])
+
+
+class _UnstackFn(Function):
+    """x [Z, ...] -> Z views x[z] (torch.unbind), with ONE gather kernel in the backward.  Slicing / indexing the stacked trunk
+    output with plain autograd costs a full-size zero-filled tensor plus an add per consumer (SelectBackward / SliceBackward:
+    ~40 launches and >1 GB of traffic per step for the 16 prompt decoders), and unbind's own backward is at::stack (not
+    hipGraph-safe on ROCm, csrc/multicopy.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        return tuple(x.unbind(0))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        shape, dtype, device = ctx.meta
+        out = torch.empty(shape, dtype=dtype, device=device)
+        n = out[0].numel()
+        live = [(i, (g if g.dtype == dtype else g.to(dtype)).contiguous()) for i, g in enumerate(gs) if g is not None]
+        for i, g in enumerate(gs):
+            if g is None:
+                out[i].zero_()
+        L.multi_copy([g for _, g in live], [i * n for i, _ in live], out)
+        return out
+
+
+def unstack(x: torch.Tensor):
+    return _UnstackFn.apply(x) if x.is_cuda else tuple(x.unbind(0))
