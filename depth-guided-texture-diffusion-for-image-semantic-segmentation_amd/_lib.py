@@ -44,6 +44,8 @@ SIGNATURES = {
     "dgtd_seg_loss_workspace": (_i64, [_i, _i]),
     "dgtd_seg_loss_fwd": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "dgtd_seg_loss_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
+    "dgtd_ssim_workspace": (_i64, []),
+    "dgtd_ssim_value": (_i, [_fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "dgtd_diffuser_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuser_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "dgtd_diffuse_tail_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),

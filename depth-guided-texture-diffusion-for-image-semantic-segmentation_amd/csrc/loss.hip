@@ -168,6 +168,91 @@ __global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ SSIM value (no gradient)
+// loss3 of cod.forward (cod.py:143-144): SSIM(minmax(x_hp), image) with SSIM._ssim (cod.py:330-348): reflect-pad 1, five 3x3 mean
+// filters, clamp((1 - n/d)/2, 0, 1), mean over channels then over everything (= the mean over all elements).  The min-max
+// normalisation e = (x_hp - min) / (max - min + 1e-8) is global, so: pass 1 = min / max of x_hp, pass 2 = the SSIM map's sum.
+// The reference runs ~30 elementwise launches on [B,3,S,S] fp32 tensors for this scalar.
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// mm[0] = ordered-uint min, mm[1] = ordered-uint max (initialised to 0xffffffff / 0 by the host-side memset pattern below)
+__global__ __launch_bounds__(256) void ssim_minmax_kernel(const float* __restrict__ x, unsigned* __restrict__ mm, long n) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += (long)gridDim.x * 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    lo = fminf(fminf(lo, v[0]), fminf(fminf(v[1], v[2]), v[3]));
+    hi = fmaxf(fmaxf(hi, v[0]), fmaxf(fmaxf(v[1], v[2]), v[3]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n - 1 - threadIdx.x]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(mm, f2ord(lo)); atomicMax(mm + 1, f2ord(hi)); }
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// one thread per pixel of one [S,S] plane; acc[0] += sum of the clamped SSIM map (double: 6 M terms)
+__global__ __launch_bounds__(256) void ssim_map_kernel(const float* __restrict__ xh, const float* __restrict__ img, const unsigned* __restrict__ mm,
+                                                       double* __restrict__ acc, int S) {
+  __shared__ double red[4];
+  const float mn = ord2f(mm[0]), mx = ord2f(mm[1]);
+  const float inv = 1.f / (mx - mn + 1e-8f);
+  const size_t plane = (size_t)blockIdx.y * S * S;
+  const float* xp = xh + plane;
+  const float* yp = img + plane;
+  float local = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < S * S; p += gridDim.x * 256) {
+    const int py = p / S, px = p % S;
+    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = reflect1(py + dy, S);
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = reflect1(px + dx, S);
+        const float a = (xp[(size_t)yy * S + xx] - mn) * inv, b = yp[(size_t)yy * S + xx];
+        sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+      }
+    }
+    const float k = 1.f / 9.f, C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu_x = sx * k, mu_y = sy * k;
+    const float sig_x = sxx * k - mu_x * mu_x, sig_y = syy * k - mu_y * mu_y, sig_xy = sxy * k - mu_x * mu_y;
+    const float nn = (2.f * mu_x * mu_y + C1) * (2.f * sig_xy + C2);
+    const float dd = (mu_x * mu_x + mu_y * mu_y + C1) * (sig_x + sig_y + C2);
+    local += fminf(fmaxf((1.f - nn / dd) * 0.5f, 0.f), 1.f);
+  }
+  double d = (double)wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void ssim_finish_kernel(const double* __restrict__ acc, float* __restrict__ out, double inv_n) { out[0] = (float)(acc[0] * inv_n); }
+
+extern "C" int64_t dgtd_ssim_workspace(void) { return 16; }
+
+// x_hp, image fp32 [B,C,S,S] (NCHW contiguous); out fp32 [1] = SSIM._ssim(minmax(x_hp), image) (cod.py:143-144, :330-348).
+// workspace: dgtd_ssim_workspace() bytes.
+extern "C" int dgtd_ssim_value(const float* x_hp, const float* image, float* out, void* workspace, int B, int C, int S, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && C > 0 && S > 1 && x_hp && image && out && workspace, "ssim_value: bad arguments");
+  DGTD_PROF(s, DGTD_HBM, 3.0 * 4 * B * C * S * S, "dgtd_ssim_value[B=%d,C=%d,S=%d]", B, C, S);
+  hipStream_t st = (hipStream_t)s;
+  unsigned* mm = (unsigned*)workspace;
+  double* acc = (double*)((char*)workspace + 8);
+  hipError_t e = hipMemsetAsync(mm, 0xff, 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync((char*)workspace + 4, 0, 12, st);
+  if (e != hipSuccess) DGTD_FAIL(3, "ssim_value: memset failed: %s", hipGetErrorString(e));
+  const long n = (long)B * C * S * S;
+  hipLaunchKernelGGL(ssim_minmax_kernel, dim3((int)std::min<long>(cdiv(n, 1024), 2048)), dim3(256), 0, st, x_hp, mm, n);
+  DGTD_CHECK_LAUNCH("ssim_minmax");
+  hipLaunchKernelGGL(ssim_map_kernel, dim3((int)std::min<long>(cdiv((long)S * S, 256), 256), B * C), dim3(256), 0, st, x_hp, image, (const unsigned*)mm, acc, S);
+  DGTD_CHECK_LAUNCH("ssim_map");
+  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1), 0, st, (const double*)acc, out, 1.0 / (double)n);
+  DGTD_CHECK_LAUNCH("ssim_finish");
+  return 0;
+}
+
 extern "C" int64_t dgtd_seg_loss_workspace(int B, int S) { return ((int64_t)B * S * S + (int64_t)5 * B * 3 + B) * sizeof(float); }
 
 // workspace layout: weit [B,S,S] | sums [5,B,3] | wsum [B]   (kept by the caller between fwd and bwd)

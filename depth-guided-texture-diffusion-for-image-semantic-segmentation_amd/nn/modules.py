@@ -823,8 +823,11 @@ class cod(nn.Module):
             # sum_it 0.2*it*cal_loss(P1[it]) + cal_loss(P2) (cod.py:137-142), up-sampling fused into the loss kernel
             loss = ops.seg_loss([*P1, P2], label, weights=(0.0, 0.2, 0.4, 0.6, 1.0))
             with torch.no_grad():
-                e = (embedding1 - embedding1.min()) / (embedding1.max() - embedding1.min() + 1e-8)
-                loss3 = ssim_value(e, input.float())
+                if input.shape[-1] == input.shape[-2]:
+                    loss3 = ops.ssim_value(embedding1, input)      # min-max normalisation + SSIM map + mean in one fused pass
+                else:
+                    e = (embedding1 - embedding1.min()) / (embedding1.max() - embedding1.min() + 1e-8)
+                    loss3 = ssim_value(e, input.float())
             return {"loss": loss + loss3}
         embedding1, P1, P2 = self._run(input, depth, x_hp)
         if mode == "predict":  # cod.py:152-153 + :219 (the PNG dumps of cod.py:156-217 are dropped)

@@ -53,3 +53,17 @@ def seg_loss(lowres_maps, label, weights=(0.0, 0.2, 0.4, 0.6, 1.0)):
     from .hitnet import stack
     lo = stack([m.float().squeeze(1) for m in lowres_maps])
     return _SegLossFn.apply(lo, label.float().contiguous(), _mix(weights, lo.device))
+
+
+def ssim_value(x_hp: torch.Tensor, image: torch.Tensor) -> torch.Tensor:
+    """loss3 of cod.forward (cod.py:143-144): SSIM(minmax(x_hp), image) with the reference's SSIM module (cod.py:316-351), value only
+    (it has no gradient path to any parameter).  fp32 [B,C,S,S] inputs, one fused pass (dgtd_ssim_value)."""
+    x = x_hp.detach().float().contiguous()
+    y = image.detach().float().contiguous()
+    L.check_cuda(x, y)
+    B, C, S, S2 = x.shape
+    assert S == S2 and y.shape == x.shape
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(16, dtype=torch.uint8, device=x.device)
+    L.call("dgtd_ssim_value", L.ptr(x), L.ptr(y), L.ptr(out), L.ptr(ws), B, C, S, L.stream_ptr())
+    return out[0]

@@ -135,6 +135,13 @@ int dgtd_seg_loss_fwd(const float* lo, const float* label, const float* mix, flo
 int dgtd_seg_loss_bwd(const float* lo, const float* label, const float* mix, const float* gout, float* dlo,
                       const void* workspace, int B, int S, int hs, dgtd_stream s);
 
+/* SSIM value of the high-pass image (cod.py:143-144 with SSIM._ssim cod.py:330-348; it has no gradient path to any parameter):
+ * out[0] = mean(clamp((1 - ssim_n/ssim_d)/2, 0, 1)) over reflect-padded 3x3 windows of e = (x_hp - min x_hp)/(max x_hp - min x_hp + 1e-8)
+ * and `image`; x_hp, image fp32 [B,C,S,S] (NCHW).  Three launches instead of ~30 elementwise passes over [B,3,S,S].
+ * workspace: dgtd_ssim_workspace() bytes.                                                                                */
+int64_t dgtd_ssim_workspace(void);
+int dgtd_ssim_value(const float* x_hp, const float* image, float* out, void* workspace, int B, int C, int S, dgtd_stream s);
+
 /* ---- Texture diffuser front end (fp32) -------------------------------------------------------
  * replaces twig/model/cod.py:1295-1298 (nearest 12x12 sample of the FFT high-pass image, 1x1 conv 3->1176,
  * sigmoid; depth 1x1 conv 1->24 + bilinear to 12x12) and MessagePassing.forward cod.py:1193-1205

@@ -606,3 +606,16 @@ def test_conv2d_gemm_matches_conv2d(dgtd, case, dtype):
     n = B * ref.shape[2] * ref.shape[3]
     assert (got[-2].float() - want[-2]).norm() / want[-2].norm() < (1e-4 if dtype == torch.float32 else 2e-2)
     torch.testing.assert_close(got[-1].float(), want[-1], atol=tol * math.sqrt(n), rtol=tol)
+
+
+@pytest.mark.parametrize("B,S", [(2, 64), (3, 96), (8, 512)])
+def test_ssim_value_vs_oracle(dgtd, B, S):
+    """dgtd_ssim_value against the oracle's SSIM module on the min-max normalised high-pass image (cod.py:143-144, :316-351)."""
+    from oracle import cod_cpu
+    g = torch.Generator().manual_seed(S)
+    x_hp = torch.rand(B, 3, S, S, generator=g) * 3.0
+    img = torch.randn(B, 3, S, S, generator=g)
+    e = (x_hp - x_hp.min()) / (x_hp.max() - x_hp.min() + 1e-8)
+    want = cod_cpu.ssim_value(e, img).item()
+    got = dgtd.ops.ssim_value(x_hp.cuda(), img.cuda()).item()
+    assert abs(got - want) < 2e-6, (got, want)
