@@ -48,8 +48,8 @@ __device__ __forceinline__ typename Vec16<T>::type load_masked(const T* __restri
 template <typename T, int CI, int NT, int MT, int TWX>
 __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ mask,
                                                           const T* __restrict__ w, const T* __restrict__ bias,
-                                                          T* __restrict__ y, int H, int W, int Co, int relu, int tiles_w,
-                                                          long x_zs, long w_zs, long y_zs) {
+                                                          T* __restrict__ y, int H, int W, int Co_full, int relu, int tiles_w,
+                                                          long x_zs, long w_zs, long y_zs, int nsplit) {
   constexpr int G = CI / 8, RW = 32 / TWX, TH = 4 * MT * RW, LW = TWX + 2, LP = (TH + 2) * LW;
   constexpr int COP = NT * 32, GP = G | 1, WSZ = COP * GP, NWR = (COP * G + 255) / 256;
   constexpr int WB = ((size_t)G * LP + 2 * WSZ) * 16 <= 65536 ? 2 : 1;   // double-buffer the kernel slices when LDS allows
@@ -60,12 +60,17 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ 
   bf16x8* tile = reinterpret_cast<bf16x8*>(smem);   // [G][LP]
   bf16x8* wbuf = tile + G * LP;                      // [WB][COP][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w, b = blockIdx.y, z = blockIdx.z;
+  // blockIdx.z = convolution z x output-channel part: with few pixel tiles (the 96- and 64-channel CAB convolutions at 64^2 and
+  // 32^2 give 256 / 64 workgroups) the NT 32-channel output tiles go to separate workgroups instead of one wave's registers:
+  // three times the workgroups per CU, the input tile is re-read from L2
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w, b = blockIdx.y, z = blockIdx.z / nsplit;
+  const int co_base = (blockIdx.z % nsplit) * (NT * 32);
+  const int Co = min(Co_full - co_base, NT * 32);        // output channels of this workgroup
   const int h0 = th * TH, w0 = tw * TWX;
   const size_t img = (size_t)b * H * W;
   const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
   const bf16_t* mb = mask ? mask + (size_t)z * x_zs + img * CI : nullptr;
-  const bf16_t* wz = w + (size_t)z * w_zs;
+  const bf16_t* wz = w + (size_t)z * w_zs + (size_t)co_base * 9 * CI;
 
   // kernel slice of one tap, [co][GP] 16-byte chunks in LDS (GP odd: the A-fragment reads of 16 consecutive lanes hit 16 different
   // 16-byte bank groups); fetched from global with channel-group-fastest indexing (CI*2 contiguous bytes per output channel)
@@ -141,13 +146,13 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ 
   }
 
   // epilogue: lane holds pixel l31 of each m-tile; registers 4q..4q+3 = output channels 8q + 4*half + {0..3}
-  const bf16_t* bz = bias ? bias + (size_t)z * Co : nullptr;
-  bf16_t* yb = y + (size_t)z * y_zs + img * Co;
+  const bf16_t* bz = bias ? bias + (size_t)z * Co_full + co_base : nullptr;
+  bf16_t* yb = y + (size_t)z * y_zs + img * Co_full + co_base;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int h = h0 + (wave * MT + mt) * RW + pr, ww = w0 + pc;
     if (h >= H || ww >= W) continue;
-    bf16_t* yp = yb + ((size_t)h * W + ww) * Co;
+    bf16_t* yp = yb + ((size_t)h * W + ww) * Co_full;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -358,15 +363,15 @@ inline FwdGeom fwd_geom(int Z, int B, int H, int W, int Ci) {
 
 template <typename T, int CI, int NT, int MT, int TWX>
 int launch_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co, int relu,
-               int shared_x, hipStream_t st) {
+               int shared_x, hipStream_t st, int nsplit = 1) {
   constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2), G = CI / 8, WSZ = NT * 32 * (G | 1);
   constexpr size_t lds = ((size_t)G * LP + ((((size_t)G * LP + 2 * WSZ) * 16 <= 65536) ? 2 : 1) * WSZ) * 16;
   static_assert(lds <= 65536, "halo tile + kernel slices exceed 64 KB of LDS");
   const int tiles_w = (int)cdiv(W, TWX), tiles_h = (int)cdiv(H, TH);
   const long plane = (long)B * H * W;
-  hipLaunchKernelGGL((conv3x3_fwd_kernel<T, CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z), dim3(256), lds, st, (const T*)x,
+  hipLaunchKernelGGL((conv3x3_fwd_kernel<T, CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z * nsplit), dim3(256), lds, st, (const T*)x,
                      (const T*)mask, (const T*)w, (const T*)bias, (T*)y, H, W, Co, relu, tiles_w,
-                     shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co);
+                     shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co, nsplit);
   DGTD_CHECK_LAUNCH("conv3x3_fwd");
   return 0;
 }
@@ -375,6 +380,14 @@ template <typename T, int CI, int NT>
 int dispatch_fwd_geom(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co,
                       int relu, int shared_x, hipStream_t st) {
   const FwdGeom g = fwd_geom(Z, B, H, W, CI);
+  if constexpr (NT > 1) {   // fewer than 2 workgroups per CU: one workgroup per 32-channel output tile
+    const long wgs = (long)Z * B * cdiv(H, 4 * (32 / g.twx)) * cdiv(W, g.twx);
+    static const bool split_on = !(getenv("DGTD_CONV3X3_SPLIT") && getenv("DGTD_CONV3X3_SPLIT")[0] == '0');
+    if (split_on && wgs < 512) {
+      if (g.twx == 16) return launch_fwd<T, CI, 1, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, NT);
+      return launch_fwd<T, CI, 1, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, NT);
+    }
+  }
   if (g.twx == 16) return launch_fwd<T, CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
   if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<T, CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
   if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<T, CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
