@@ -115,14 +115,17 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
-        with _no_cat(), torch.cuda.graph(self.graph_fb, stream=s):
+        # with a process group alive, RCCL's watchdog thread keeps querying events while we capture: only this thread's (and the
+        # autograd thread's, which launches into the capturing stream) calls must obey capture rules
+        mode = "thread_local" if self.split else "global"
+        with _no_cat(), torch.cuda.graph(self.graph_fb, stream=s, capture_error_mode=mode):
             self.loss = self._fwd_bwd()
             self._gather_all()
             if not self.split:
                 self.opt.step()
         if self.split:
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, stream=s, pool=self.graph_fb.pool()):
+            with torch.cuda.graph(self.graph_opt, stream=s, pool=self.graph_fb.pool(), capture_error_mode=mode):
                 self.opt.step()
         torch.cuda.synchronize()
 
