@@ -25,6 +25,11 @@ SIGNATURES = {
     "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
     "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
     "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
+    "dgtd_layernorm_bwd_partial": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _vp, _vp, _i64, _i, _i, C.POINTER(C.c_int), _vp]),
+    "dgtd_multi_reduce": (_i, [_vp, _i, _vp]),
+    "dgtd_scale_residual_bias_bwd_partial": (_i, [_vp, _vp, _fp, _fp, _vp, _vp, _i64, _i, _i64, _i, C.POINTER(C.c_int), _vp]),
+    "dgtd_gelu_bias_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.POINTER(C.c_int), _vp]),
+    "dgtd_colsum_partial": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_int), _vp]),
     "dgtd_layernorm_bwd_add": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),
     "dgtd_sra_attn_fwd": (_i, [_vp, _vp, _vp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
     "dgtd_sra_attn_bwd_workspace": (_i64, [_i, _i, _i]),

@@ -504,7 +504,9 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
     // of the whole dK/dV (the chip-wide atomic rate is ~1.3 TB/s).  With a single chunk the result is stored plainly.
     const int kgroups = (int)cdiv(Nkv, KGROUP);
     DGTD_REQUIRE((int64_t)heads * kgroups <= 65535, "sra_attn_bwd: heads*kgroups too large for the grid");
-    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(256, (int64_t)B * heads * kgroups)));
+    // 512 workgroups = two waves per SIMD: 75 -> 63 us at stage 1 (B=8, N=16384); 1024 loses again to the extra atomic flushes (81 us)
+    static const int64_t wg_target = getenv("DGTD_DKDV_WGS") ? atol(getenv("DGTD_DKDV_WGS")) : 512;
+    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(wg_target, (int64_t)B * heads * kgroups)));
     const int qch = (int)cdiv(qtiles, nq);
     const int nqc = (int)cdiv(qtiles, qch);
     DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL(sra_bwd_dkdv_bf16<T_>, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const T_*)q, (const T_*)kv,

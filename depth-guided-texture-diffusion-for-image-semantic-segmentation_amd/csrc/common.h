@@ -123,3 +123,7 @@ __device__ __forceinline__ float gelu_fast(float x) { float pdf; return x * gelu
 __device__ __forceinline__ float gelu_grad_fast(float x) { float pdf; const float phi = gelu_phi(x, &pdf); return fmaf(x, pdf, phi); }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// second stage of every two-stage column reduction (LayerNorm dgamma/dbeta, Linear bias gradients, layer-scale gradients): see
+// dgtd_multi_reduce in elementwise.hip.  One entry = one partial buffer ws[nblocks][ncols] summed over its rows in a fixed order.
+int dgtd_multi_reduce_impl(const dgtd_reduce_entry* entries, int n, hipStream_t st);

@@ -93,30 +93,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
   }
 }
 
-// ws [nblocks][C] -> out[C] (out_bf16 = dtype code of out: DGTD_F32 / DGTD_BF16 / DGTD_F16); one workgroup per 32 columns x 8 row groups, fixed summation order
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, void* __restrict__ out, int out_bf16, int nblocks, int C) {
+// ---- multi-reduce: the second stage of every two-stage column reduction of the library ------------------------------------------
+// One workgroup = 32 columns x 8 row groups of ONE entry (a narrow tile: the partial buffers are small and the work latency-bound);
+// row group g sums rows g, g+8, ... with 8 loads in flight, the groups meet in LDS.  Fixed summation order.  The entry table travels
+// by value in the kernel arguments (hipGraph-safe).
+constexpr int MR_MAX = 56;
+struct MrTable {
+  const float* ws[MR_MAX];
+  float* outA[MR_MAX];
+  void* outB[MR_MAX];
+  int nblocks[MR_MAX], ncols[MR_MAX], nA[MR_MAX], dtB[MR_MAX];
+  int first_tile[MR_MAX + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void multi_reduce_kernel(MrTable t) {
   __shared__ float part[8][32];
+  const int tile = blockIdx.x;
+  int lo = 0, hi = t.count;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.first_tile[mid] <= tile) lo = mid; else hi = mid; }
+  const int e = lo;
   const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + lane;
+  const int col = (tile - t.first_tile[e]) * 32 + lane;
+  const int ncols = t.ncols[e], nblocks = t.nblocks[e], nA = t.nA[e];
+  const bool live = col < ncols && (col >= nA || t.outA[e] != nullptr);
   float s0 = 0.f, s1 = 0.f;
-  if (col < C) {
-    const float* p = ws + col;
+  if (live) {
+    const float* p = t.ws[e] + col;
+    const size_t rs = (size_t)ncols;
     int b = rgp;
-    for (; b + 24 < nblocks; b += 32) {
-      s0 += p[(size_t)b * C] + p[(size_t)(b + 8) * C];
-      s1 += p[(size_t)(b + 16) * C] + p[(size_t)(b + 24) * C];
+    for (; b + 56 < nblocks; b += 64) {
+      const float v0 = p[(size_t)b * rs], v1 = p[(size_t)(b + 8) * rs], v2 = p[(size_t)(b + 16) * rs], v3 = p[(size_t)(b + 24) * rs];
+      const float v4 = p[(size_t)(b + 32) * rs], v5 = p[(size_t)(b + 40) * rs], v6 = p[(size_t)(b + 48) * rs], v7 = p[(size_t)(b + 56) * rs];
+      s0 += ((v0 + v1) + (v2 + v3));
+      s1 += ((v4 + v5) + (v6 + v7));
     }
-    for (; b < nblocks; b += 8) s0 += p[(size_t)b * C];
+    for (; b < nblocks; b += 8) s0 += p[(size_t)b * rs];
   }
   part[rgp][lane] = s0 + s1;
   __syncthreads();
-  if (rgp == 0 && col < C) {
+  if (rgp == 0 && live) {
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v += part[k][lane];
-    if (out_bf16 == DGTD_BF16) ((bf16_t*)out)[col] = (bf16_t)v;
-    else if (out_bf16 == DGTD_F16) ((f16_t*)out)[col] = (f16_t)v;
-    else ((float*)out)[col] = v;
+    if (col < nA) t.outA[e][col] = v;
+    else if (t.dtB[e] == DGTD_BF16) ((bf16_t*)t.outB[e])[col - nA] = (bf16_t)v;
+    else if (t.dtB[e] == DGTD_F16) ((f16_t*)t.outB[e])[col - nA] = (f16_t)v;
+    else ((float*)t.outB[e])[col - nA] = v;
   }
 }
 
@@ -127,9 +150,10 @@ int check_c(int C, const char* who) {
   return 0;
 }
 
+// first stage: ws [*nblocks][C] partial rows (MODE 2 writes none); `out` (dtype code out_dt) is reduced here unless nblocks != NULL
 template <typename T, int MODE>
 int colsum_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, void* out, void* ws, int64_t rows,
-                  int C, int64_t rps, hipStream_t st, const char* who, int out_bf16 = 0) {
+                  int C, int64_t rps, hipStream_t st, const char* who, int out_dt = 0, int* nblocks = nullptr) {
   if (int rc = check_c<T>(C, who)) return rc;
   constexpr int V = Vec16<T>::N;
   const int CV = C / V, ncb = (int)cdiv(CV, 256);
@@ -138,9 +162,11 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
   const size_t lds = (size_t)256 * V * sizeof(float);
   hipLaunchKernelGGL((colsum_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
+  if (nblocks) { *nblocks = gx; return 0; }
   if (MODE != 2) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((int)cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, out, out_bf16, gx, C);
-    DGTD_CHECK_LAUNCH(who);
+    const dgtd_reduce_entry e{(const float*)ws, gx, C, out_dt == DGTD_F32 ? (float*)out : nullptr, out_dt == DGTD_F32 ? C : 0,
+                              out_dt == DGTD_F32 ? nullptr : out, out_dt};
+    return dgtd_multi_reduce_impl(&e, 1, st);
   }
   return 0;
 }
@@ -212,42 +238,9 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ g, c
   }
 }
 
-// ws [nblocks][2C] -> outA[C] fp32 (columns < C; skipped when outA is NULL) and outB[C] (fp32 or bf16); fixed summation order
-__global__ __launch_bounds__(256) void colsum2_reduce_kernel(const float* __restrict__ ws, float* __restrict__ outA, void* __restrict__ outB,
-                                                             int outB_bf16, int nblocks, int C) {
-  // 32 columns x 8 row groups per workgroup: twice the workgroups of a 64-column layout (the partial buffer is small, the kernel
-  // is latency-bound), 128-byte contiguous reads per row group
-  __shared__ float part[8][32];
-  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + lane;              // over 2C columns
-  const bool live = col < 2 * C && (col >= C || outA != nullptr);
-  float s0 = 0.f, s1 = 0.f;
-  if (live) {
-    const float* p = ws + col;
-    const size_t rs = (size_t)2 * C;
-    int b = rgp;
-    for (; b + 24 < nblocks; b += 32) {
-      s0 += p[b * rs] + p[(b + 8) * rs];
-      s1 += p[(b + 16) * rs] + p[(b + 24) * rs];
-    }
-    for (; b < nblocks; b += 8) s0 += p[b * rs];
-  }
-  part[rgp][lane] = s0 + s1;
-  __syncthreads();
-  if (rgp == 0 && live) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v += part[k][lane];
-    if (col < C) outA[col] = v;
-    else if (outB_bf16 == DGTD_BF16) ((bf16_t*)outB)[col - C] = (bf16_t)v;
-    else if (outB_bf16 == DGTD_F16) ((f16_t*)outB)[col - C] = (f16_t)v;
-    else ((float*)outB)[col - C] = v;
-  }
-}
-
 template <typename T, int MODE>
 int colsum2_launch(const void* g, const void* y, const float* s, const float* gamma, void* dy, float* outA, void* outB, int outB_bf16,
-                   void* ws, int64_t rows, int C, int64_t rps, hipStream_t st, const char* who) {
+                   void* ws, int64_t rows, int C, int64_t rps, hipStream_t st, const char* who, int* nblocks = nullptr) {
   if (int rc = check_c<T>(C, who)) return rc;
   constexpr int V = Vec16<T>::N;
   const int CV = C / V, ncb = (int)cdiv(CV, 256);
@@ -256,12 +249,73 @@ int colsum2_launch(const void* g, const void* y, const float* s, const float* ga
   const size_t lds = (size_t)256 * V * sizeof(float);
   hipLaunchKernelGGL((colsum2_kernel<T, MODE>), dim3(gx, ncb), dim3(256), lds, st, (const T*)g, (const T*)y, s, gamma, (T*)dy, (float*)ws, rows, C, rps);
   DGTD_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(colsum2_reduce_kernel, dim3((int)cdiv(2 * C, 32)), dim3(256), 0, st, (const float*)ws, outA, outB, outB_bf16, gx, C);
-  DGTD_CHECK_LAUNCH(who);
-  return 0;
+  if (nblocks) { *nblocks = gx; return 0; }
+  // columns [0, C) = dgamma partials (garbage when the kernel had no gamma: then outA is NULL and they are skipped), [C, 2C) = dbias
+  const dgtd_reduce_entry e{(const float*)ws, gx, 2 * C, outA, C, outB, outB_bf16};
+  return dgtd_multi_reduce_impl(&e, 1, st);
 }
 
 }  // namespace
+
+int dgtd_multi_reduce_impl(const dgtd_reduce_entry* entries, int n, hipStream_t st) {
+  for (int b0 = 0; b0 < n; b0 += MR_MAX) {
+    MrTable t;
+    const int m = std::min(MR_MAX, n - b0);
+    t.count = m;
+    int tiles = 0;
+    for (int i = 0; i < m; ++i) {
+      const dgtd_reduce_entry& e = entries[b0 + i];
+      DGTD_REQUIRE(e.ws && e.nblocks > 0 && e.ncols > 0 && e.nA >= 0 && e.nA <= e.ncols && (e.nA == e.ncols || e.outB), "multi_reduce: bad entry %d", b0 + i);
+      t.ws[i] = e.ws; t.outA[i] = e.outA; t.outB[i] = e.outB; t.nblocks[i] = e.nblocks; t.ncols[i] = e.ncols; t.nA[i] = e.nA; t.dtB[i] = e.dtB;
+      t.first_tile[i] = tiles;
+      tiles += (int)cdiv(e.ncols, 32);
+    }
+    for (int i = m; i <= MR_MAX; ++i) t.first_tile[i] = tiles;
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(tiles), dim3(256), 0, st, t);
+    DGTD_CHECK_LAUNCH("multi_reduce");
+  }
+  return 0;
+}
+
+extern "C" int dgtd_multi_reduce(const dgtd_reduce_entry* entries, int n, dgtd_stream s) {
+  DGTD_REQUIRE(n >= 0 && (n == 0 || entries), "multi_reduce: bad arguments");
+  if (n == 0) return 0;
+  double bytes = 0;
+  for (int i = 0; i < n; ++i) bytes += 4.0 * entries[i].nblocks * entries[i].ncols;
+  DGTD_PROF(s, DGTD_HBM, bytes, "dgtd_multi_reduce[n=%d]", n);
+  return dgtd_multi_reduce_impl(entries, n, (hipStream_t)s);
+}
+
+extern "C" int dgtd_scale_residual_bias_bwd_partial(const void* g, const void* y, const float* s, const float* gamma, void* dy, void* workspace,
+                                                    int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, int* nblocks, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && rows_per_sample > 0 && nblocks, "scale_residual_bias_bwd_partial: bad sizes");
+  DGTD_PROF(st, DGTD_HBM, (gamma ? 3.0 : 2.0) * dgtd_esize(dt) * rows * C, "dgtd_scale_residual_bias_bwd[rows=%lld,C=%d]", (long long)rows, C);
+  hipStream_t h = (hipStream_t)st;
+  if (dt == DGTD_F16) return colsum2_launch<f16_t, 3>(g, y, s, gamma, dy, nullptr, nullptr, 0, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd", nblocks);
+  if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 3>(g, y, s, gamma, dy, nullptr, nullptr, 0, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd", nblocks);
+  if (dt == DGTD_F32) return colsum2_launch<float, 3>(g, y, s, gamma, dy, nullptr, nullptr, 0, workspace, rows, C, rows_per_sample, h, "scale_residual_bias_bwd", nblocks);
+  DGTD_FAIL(2, "scale_residual_bias_bwd_partial: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_gelu_bias_bwd_partial(const void* g, const void* pre, void* dpre, void* workspace, int64_t rows, int C, dgtd_dtype dt,
+                                          int* nblocks, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && nblocks, "gelu_bias_bwd_partial: bad sizes");
+  DGTD_PROF(st, DGTD_HBM, 3.0 * dgtd_esize(dt) * rows * C, "dgtd_gelu_bias_bwd[rows=%lld,C=%d]", (long long)rows, C);
+  hipStream_t h = (hipStream_t)st;
+  if (dt == DGTD_F16) return colsum2_launch<f16_t, 4>(g, pre, nullptr, nullptr, dpre, nullptr, nullptr, 0, workspace, rows, C, 1, h, "gelu_bias_bwd", nblocks);
+  if (dt == DGTD_BF16) return colsum2_launch<bf16_t, 4>(g, pre, nullptr, nullptr, dpre, nullptr, nullptr, 0, workspace, rows, C, 1, h, "gelu_bias_bwd", nblocks);
+  if (dt == DGTD_F32) return colsum2_launch<float, 4>(g, pre, nullptr, nullptr, dpre, nullptr, nullptr, 0, workspace, rows, C, 1, h, "gelu_bias_bwd", nblocks);
+  DGTD_FAIL(2, "gelu_bias_bwd_partial: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_colsum_partial(const void* x, void* workspace, int64_t rows, int C, dgtd_dtype dt, int* nblocks, dgtd_stream st) {
+  DGTD_REQUIRE(rows > 0 && C > 0 && nblocks, "colsum_partial: bad sizes");
+  DGTD_PROF(st, DGTD_HBM, 1.0 * dgtd_esize(dt) * rows * C, "dgtd_colsum[rows=%lld,C=%d]", (long long)rows, C);
+  if (dt == DGTD_F16) return colsum_launch<f16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, rows, C, 1, (hipStream_t)st, "colsum", 0, nblocks);
+  if (dt == DGTD_BF16) return colsum_launch<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, rows, C, 1, (hipStream_t)st, "colsum", 0, nblocks);
+  if (dt == DGTD_F32) return colsum_launch<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, rows, C, 1, (hipStream_t)st, "colsum", 0, nblocks);
+  DGTD_FAIL(2, "colsum_partial: bad dtype %d", (int)dt);
+}
 
 extern "C" int dgtd_scale_residual_fwd(const void* x, const void* y, const float* s, const float* gamma, void* out, int64_t rows,
                                        int C, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st) {

@@ -210,37 +210,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// ws is [nblocks][2*C]; one workgroup sums 64 columns: wave w takes rows w, w+4, ... (256-B coalesced row segments),
-// the four waves meet in LDS.  Deterministic (fixed summation order), unlike an atomic flush.
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int nblocks, int C) {
-  // 32 columns x 8 row groups per workgroup (the partial buffer is small and the kernel latency-bound: more, narrower workgroups)
-  __shared__ float part[8][32];
-  const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + lane;
-  float s0 = 0.f, s1 = 0.f;
-  if (col < 2 * C) {
-    const size_t rs = (size_t)2 * C;
-    const float* p = ws + col;
-    int b = rgp;
-    for (; b + 56 < nblocks; b += 64) {   // 8 independent loads in flight per lane, fixed summation order
-      const float v0 = p[(size_t)b * rs], v1 = p[(size_t)(b + 8) * rs], v2 = p[(size_t)(b + 16) * rs], v3 = p[(size_t)(b + 24) * rs];
-      const float v4 = p[(size_t)(b + 32) * rs], v5 = p[(size_t)(b + 40) * rs], v6 = p[(size_t)(b + 48) * rs], v7 = p[(size_t)(b + 56) * rs];
-      s0 += ((v0 + v1) + (v2 + v3));
-      s1 += ((v4 + v5) + (v6 + v7));
-    }
-    for (; b < nblocks; b += 8) s0 += p[(size_t)b * rs];
-  }
-  part[rgp][lane] = s0 + s1;
-  __syncthreads();
-  if (rgp == 0 && col < 2 * C) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += part[k][lane];
-    if (col < C) dgamma[col] = s; else dbeta[col - C] = s;
-  }
-}
-
 struct LnGeom { int G, npl; int64_t rows_per_block; };
 template <typename T> LnGeom ln_geom(int C) {
   int cpr = C / Vec16<T>::N;
@@ -268,7 +237,7 @@ int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y,
 
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                  float* dgamma, float* dbeta, void* ws, int64_t rows, int C, hipStream_t s, const void* dres = nullptr) {
+                  float* dgamma, float* dbeta, void* ws, int64_t rows, int C, hipStream_t s, const void* dres = nullptr, int* nblocks = nullptr) {
   DGTD_REQUIRE(C % Vec16<T>::N == 0, "layernorm: C=%d must be a multiple of %d", C, Vec16<T>::N);
   LnGeom g = ln_geom<T>(C);
   DGTD_REQUIRE(g.npl <= LN_MAX_NPL, "layernorm: C=%d too large", C);
@@ -279,9 +248,9 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
   switch (g.npl) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; default: LN_BWD(4); }
 #undef LN_BWD
   DGTD_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((int)cdiv(2 * C, 32)), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, grid, C);
-  DGTD_CHECK_LAUNCH("layernorm_bwd_reduce");
-  return 0;
+  if (nblocks) { *nblocks = grid; return 0; }
+  const dgtd_reduce_entry e{(const float*)ws, grid, 2 * C, dgamma, C, dbeta, DGTD_F32};     // ws [grid][2C] = { dgamma | dbeta } partial rows
+  return dgtd_multi_reduce_impl(&e, 1, s);
 }
 
 }  // namespace
@@ -303,6 +272,17 @@ extern "C" int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float
   if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, C, (hipStream_t)s, dx_add);
   DGTD_FAIL(2, "layernorm_bwd_add: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                          const void* dx_add, void* dx, void* workspace, int64_t rows, int C, dgtd_dtype dt, int* nblocks,
+                                          dgtd_stream s) {
+  DGTD_REQUIRE(nblocks, "layernorm_bwd_partial: nblocks is NULL");
+  DGTD_PROF(s, DGTD_HBM, (dx_add ? 4.0 : 3.0) * dgtd_esize(dt) * rows * C, "dgtd_layernorm_bwd[rows=%lld,C=%d]", (long long)rows, C);
+  if (dt == DGTD_F32) return ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, C, (hipStream_t)s, dx_add, nblocks);
+  if (dt == DGTD_BF16) return ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, C, (hipStream_t)s, dx_add, nblocks);
+  if (dt == DGTD_F16) return ln_bwd_launch<f16_t>(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, C, (hipStream_t)s, dx_add, nblocks);
+  DGTD_FAIL(2, "layernorm_bwd_partial: bad dtype %d", (int)dt);
 }
 
 extern "C" int64_t dgtd_layernorm_bwd_workspace(int C) { return (int64_t)LN_BWD_MAX_GRID * 2 * C * sizeof(float); }

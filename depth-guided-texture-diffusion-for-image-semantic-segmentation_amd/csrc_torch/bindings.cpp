@@ -3,7 +3,10 @@
 // pointers on the current HIP stream, one autograd node per op.  Host plumbing only (no device code here): it exists because the
 // training step is host-bound in eager Python (~1600 Python autograd.Function calls per step); these nodes cost a few microseconds.
 #include <ATen/ATen.h>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include <c10/hip/HIPStream.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
@@ -33,6 +36,51 @@ inline at::ScalarType from_code(int64_t dt_code) { return dt_code == DGTD_BF16 ?
 inline int64_t st_id(const Tensor& t) { return (int64_t)t.scalar_type(); }                  // a dtype remembered across forward -> backward
 inline at::ScalarType st_of(const c10::IValue& v) { return (at::ScalarType)v.toInt(); }
 
+// ------------------------------------------------------------------------------------------------ deferred second-stage reductions
+// Every backward node that also produces a per-column sum (LayerNorm dgamma/dbeta, Linear bias gradients, layer-scale gradients) needs
+// a second pass over its per-workgroup partial rows: ~290 launches of ~6 us per training step.  Between `set_deferred(true)` and the
+// next `flush_deferred()` (the gradient reducer brackets backward() with them, dist/reducer.py) the nodes run only their first stage,
+// hand out the still unwritten gradient tensors and park (partial buffer, destination) here; ONE dgtd_multi_reduce per 56 entries then
+// fills them all.  Nothing may read those gradients before the flush: the reducer's gather does so only after it, and parameters
+// shared between call sites (autograd adds their gradients on the fly) never take this path (only LayerNorm, Linear bias and gamma
+// gradients of the two trunks do; their parameters are used once per step).  Destinations are remembered as raw pointers: holding the
+// tensors would stop AccumulateGrad from stealing them (it would clone the unwritten memory instead).
+struct PendingReduce { dgtd_reduce_entry e; Tensor ws; };
+static std::mutex g_pending_mu;
+static std::vector<PendingReduce> g_pending;
+static std::atomic<bool> g_defer{false};
+
+inline bool deferring() { return g_defer.load(std::memory_order_relaxed); }
+inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, void* outB, dgtd_dtype dtB) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_pending.push_back(PendingReduce{dgtd_reduce_entry{ws.data_ptr<float>(), nblocks, ncols, outA, nA, outB, (int32_t)dtB}, ws});
+}
+void flush_deferred() {
+  std::vector<PendingReduce> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    todo.swap(g_pending);
+  }
+  if (todo.empty()) return;
+  std::vector<dgtd_reduce_entry> es;
+  es.reserve(todo.size());
+  for (auto& p : todo) es.push_back(p.e);
+  check(dgtd_multi_reduce(es.data(), (int)es.size(), stream()), "dgtd_multi_reduce");
+}
+void set_deferred(bool on) {
+  if (on) {   // entries left over from a backward that was never flushed point at dead memory: drop them
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    g_pending.clear();
+  } else {
+    flush_deferred();
+  }
+  g_defer.store(on);
+}
+int64_t pending_reductions() {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  return (int64_t)g_pending.size();
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w, const Tensor& b, double eps) {
@@ -55,10 +103,17 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
     if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
     Tensor dx = at::empty_like(x);
     Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
-    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C)}, x.options().dtype(at::kByte));
-    check(dgtd_layernorm_bwd(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
-                             dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C, ws.data_ptr(), rows, (int)C, code(x), stream()),
-          "dgtd_layernorm_bwd");
+    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C) / 4}, x.options().dtype(at::kFloat));
+    if (deferring()) {
+      int nb = 0;
+      check(dgtd_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                                       nullptr, dx.data_ptr(), ws.data_ptr(), rows, (int)C, code(x), &nb, stream()), "dgtd_layernorm_bwd_partial");
+      park(ws, nb, 2 * (int)C, dgb.data_ptr<float>(), 2 * (int)C, nullptr, DGTD_F32);
+    } else {
+      check(dgtd_layernorm_bwd(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                               dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C, ws.data_ptr(), rows, (int)C, code(x), stream()),
+            "dgtd_layernorm_bwd");
+    }
     return {dx, dgb[0], dgb[1], undefined()};
   }
 };
@@ -90,10 +145,18 @@ struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
     if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
     Tensor dx = at::empty_like(x);
     Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
-    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C)}, x.options().dtype(at::kByte));
-    check(dgtd_layernorm_bwd_add(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
-                                 dres.defined() ? dres.data_ptr() : nullptr, dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C,
-                                 ws.data_ptr(), rows, (int)C, code(x), stream()), "dgtd_layernorm_bwd_add");
+    Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C) / 4}, x.options().dtype(at::kFloat));
+    if (deferring()) {
+      int nb = 0;
+      check(dgtd_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                                       dres.defined() ? dres.data_ptr() : nullptr, dx.data_ptr(), ws.data_ptr(), rows, (int)C, code(x), &nb, stream()),
+            "dgtd_layernorm_bwd_partial");
+      park(ws, nb, 2 * (int)C, dgb.data_ptr<float>(), 2 * (int)C, nullptr, DGTD_F32);
+    } else {
+      check(dgtd_layernorm_bwd_add(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
+                                   dres.defined() ? dres.data_ptr() : nullptr, dx.data_ptr(), dgb.data_ptr<float>(), dgb.data_ptr<float>() + C,
+                                   ws.data_ptr(), rows, (int)C, code(x), stream()), "dgtd_layernorm_bwd_add");
+    }
     return {dx, dgb[0], dgb[1], undefined()};
   }
 };
@@ -273,8 +336,15 @@ Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
   const int64_t rows = x2.size(0), C = x2.size(1);
   if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat).to(out_dt);   // narrower than a 16-byte chunk per lane
   Tensor out = at::empty({C}, x2.options().dtype(out_dt));
-  Tensor ws = at::empty({dgtd_colsum_workspace((int)C)}, x2.options().dtype(at::kByte));
-  check(dgtd_colsum(x2.data_ptr(), out.data_ptr(), code(out), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
+  Tensor ws = at::empty({dgtd_colsum_workspace((int)C) / 4}, x2.options().dtype(at::kFloat));
+  if (deferring()) {
+    int nb = 0;
+    check(dgtd_colsum_partial(x2.data_ptr(), ws.data_ptr(), rows, (int)C, code(x2), &nb, stream()), "dgtd_colsum_partial");
+    const bool f = out_dt == at::kFloat;
+    park(ws, nb, (int)C, f ? out.data_ptr<float>() : nullptr, f ? (int)C : 0, f ? nullptr : out.data_ptr(), code(out));
+  } else {
+    check(dgtd_colsum(x2.data_ptr(), out.data_ptr(), code(out), ws.data_ptr(), rows, (int)C, code(x2), stream()), "dgtd_colsum");
+  }
   return out;
 }
 
@@ -392,9 +462,16 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor dh = as_rows(g[0], pre.scalar_type());
     const int64_t rows = pre.size(0), C = pre.size(1);
     Tensor dpre = at::empty_like(pre), db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
-    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, pre.options().dtype(at::kByte));
-    check(dgtd_gelu_bias_bwd(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), code(db), ws.data_ptr(), rows, (int)C, code(pre),
-                             stream()), "dgtd_gelu_bias_bwd");
+    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, pre.options().dtype(at::kFloat));
+    if (deferring()) {
+      int nb = 0;
+      check(dgtd_gelu_bias_bwd_partial(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), ws.data_ptr(), rows, (int)C, code(pre), &nb, stream()),
+            "dgtd_gelu_bias_bwd_partial");
+      park(ws, nb, 2 * (int)C, nullptr, (int)C, db.data_ptr(), code(db));
+    } else {
+      check(dgtd_gelu_bias_bwd(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), code(db), ws.data_ptr(), rows, (int)C, code(pre),
+                               stream()), "dgtd_gelu_bias_bwd");
+    }
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
     Tensor dw = gemm_dw(dpre, x2);
@@ -439,10 +516,19 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     const int64_t rows = y.size(0), C = y.size(1), B = m[6];
     Tensor dy = at::empty_like(y), db = at::empty({C}, y.options().dtype(b_dt));
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
-    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C)}, y.options().dtype(at::kByte));
-    check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
-                                       dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, db.data_ptr(), code(db), ws.data_ptr(), rows,
-                                       (int)C, rows / B, code(y), stream()), "dgtd_scale_residual_bias_bwd");
+    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, y.options().dtype(at::kFloat));
+    // the layer-scale gradient is deferred only when it needs no dtype conversion afterwards (gamma is an fp32 parameter on this path)
+    if (deferring() && (!has_g || g_dt == at::kFloat)) {
+      int nb = 0;
+      check(dgtd_scale_residual_bias_bwd_partial(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr,
+                                                 has_g ? g32.data_ptr<float>() : nullptr, dy.data_ptr(), ws.data_ptr(), rows, (int)C, rows / B,
+                                                 code(y), &nb, stream()), "dgtd_scale_residual_bias_bwd_partial");
+      park(ws, nb, 2 * (int)C, has_g ? dgamma.data_ptr<float>() : nullptr, (int)C, db.data_ptr(), code(db));
+    } else {
+      check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                         dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, db.data_ptr(), code(db), ws.data_ptr(), rows,
+                                         (int)C, rows / B, code(y), stream()), "dgtd_scale_residual_bias_bwd");
+    }
     Tensor dh;
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
     Tensor dw = gemm_dw(dy, h2);
@@ -655,4 +741,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);
   m.def("ca_gate(Tensor res, Tensor x, Tensor w1, Tensor w2) -> Tensor", &ca_gate);
   m.def("bilinear_resize(Tensor x, int oh, int ow, bool align) -> Tensor", &bilinear_resize);
+  m.def("set_deferred(bool on) -> ()", &set_deferred);
+  m.def("flush_deferred() -> ()", &flush_deferred);
+  m.def("pending_reductions() -> int", &pending_reductions);
 }

@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 # constructed but never called in the reference forward (cod.py:703-704, :1251): no gradient, ever
 STATIC_UNUSED = ("hitnet.backbone.prompt_encoder.adaptor.", "hitnet.ca.", "hitnet.sa.")
+DEFER = os.environ.get("DGTD_DEFER_REDUCTIONS", "1") != "0"   # A/B switch: batched second-stage column reductions
 ALIGN = 8   # elements: every tensor of a bucket starts on a 16-byte (2-byte dtypes) / 32-byte (fp32) boundary
 
 
@@ -203,6 +204,23 @@ class GradReducer:
             b["pending"], b["done"], b["ready"] = b["n"], False, False
             for leaf in b["leaves"]:
                 leaf.grad = None
+        self._defer(True)
+
+    def _defer(self, on: bool) -> None:
+        """Bracket backward(): while on, the C++ backward nodes park the second stage of their column reductions (LayerNorm
+        dgamma/dbeta, Linear bias gradients) and ONE dgtd_multi_reduce per 56 of them runs at the first gather (csrc_torch/bindings.cpp)."""
+        if self._cuda and DEFER:
+            from ..ops import _native
+            nat = _native.ops()
+            if nat is not None:
+                nat.set_deferred(on)
+
+    def _flush_deferred(self) -> None:
+        if self._cuda and DEFER:
+            from ..ops import _native
+            nat = _native.ops()
+            if nat is not None:
+                nat.flush_deferred()
 
     def _make_hook(self, bucket):
         def hook(_leaf):
@@ -234,6 +252,7 @@ class GradReducer:
     def _gather(self, bucket) -> None:
         """Leaf gradients -> flat fp32 bucket: one batched concat per dtype segment (+ one cast for the
         low-precision segment) instead of a copy kernel per parameter; then restore the master .grad views."""
+        self._flush_deferred()          # parked column reductions write their gradients now (no-op when none are pending)
         flat, k, nw = bucket["flat"], bucket["k_work"], bucket["n_work"]
         leaves, gviews, nhwc = bucket["leaves"], bucket["gviews"], bucket["nhwc"]
         sizes, padded = bucket["sizes"], bucket["padded"]
@@ -312,6 +331,7 @@ class GradReducer:
             self._gather(b)
             self._launch(b)
         self._next = len(self.buckets)
+        self._defer(False)
         for w in self._works:
             w.wait()
         self._works.clear()

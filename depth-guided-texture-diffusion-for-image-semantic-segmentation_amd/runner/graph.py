@@ -81,6 +81,7 @@ class GraphedTrainStep:
         for b in r.buckets[r._next:]:
             r._gather(b)
         r._next = len(r.buckets)
+        r._defer(False)
 
     def _allreduce_all(self) -> None:
         r = self.reducer

@@ -59,6 +59,10 @@ int dgtd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
 int dgtd_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                            const void* dx_add, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows,
                            int C, dgtd_dtype dt, dgtd_stream s);
+/* First stage only: workspace receives [*nblocks][2C] = { dgamma | dbeta } partial rows (see dgtd_multi_reduce).                 */
+int dgtd_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                               const void* dx_add, void* dx, void* workspace, int64_t rows, int C, dgtd_dtype dt, int* nblocks,
+                               dgtd_stream s);
 
 /* ---- Spatial-reduction multi-head attention core: softmax(Q K^T * scale) V, head_dim = 64 -----
  * replaces twig/model/cod.py:913-917 (the q/kv/proj Linears stay GEMM calls).
@@ -96,6 +100,23 @@ int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K);
 int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace,
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
 
+/* ---- Second stage of the two-stage column reductions, for MANY reductions in one launch --------------------------------------
+ * The backward kernels below that also produce a per-column sum (LayerNorm dgamma/dbeta, the bias gradient of every nn.Linear, the
+ * layer-scale gradient) write one partial row per workgroup and need a second pass over [nblocks][ncols].  The plain entry points
+ * run that pass themselves; their `_partial` siblings stop after the first stage and report `nblocks`, so that a caller can run the
+ * second stage of a whole backward pass (≈ 290 reductions per training step) in a handful of launches with dgtd_multi_reduce.
+ * One entry: out columns [0, nA) of the row sum go to outA as fp32 (skipped when outA is NULL), columns [nA, ncols) to outB in dtB.
+ * Fixed summation order (deterministic), identical to what the plain entry points produce.  entries: HOST array.                  */
+typedef struct {
+  const float* ws;   /* partial rows [nblocks][ncols], fp32 */
+  int32_t nblocks, ncols;
+  float* outA;       /* fp32 [nA] or NULL */
+  int32_t nA;
+  void* outB;        /* [ncols - nA] in dtB, or NULL when nA == ncols */
+  int32_t dtB;       /* dgtd_dtype */
+} dgtd_reduce_entry;
+int dgtd_multi_reduce(const dgtd_reduce_entry* entries, int n, dgtd_stream s);
+
 /* ---- Fused residual epilogue and column sums on [rows, C] token matrices -------------------------
  * out = x + s[b] * gamma[c] * y : convnext_Block tail (gamma*x, DropPath, residual; twig/model/cod.py:1112-1116) and the
  * Block residuals x + DropPath(.) (cod.py:958-959).  s fp32 [B] = per-sample stochastic-depth scale (0 or 1/keep) or NULL;
@@ -118,6 +139,13 @@ int dgtd_scale_residual_bias_bwd(const void* g, const void* y, const float* s, c
                                  int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream st);
 int dgtd_gelu_bias_bwd(const void* g, const void* pre, void* dpre, void* dbias, dgtd_dtype bias_dt, void* workspace,
                        int64_t rows, int C, dgtd_dtype dt, dgtd_stream st);
+/* First stages only: workspace receives [*nblocks][2C] = { dgamma partials (zero columns when gamma is NULL / for the GELU form) |
+ * dbias partials }; [*nblocks][C] for dgtd_colsum_partial.                                                                        */
+int dgtd_scale_residual_bias_bwd_partial(const void* g, const void* y, const float* s, const float* gamma, void* dy, void* workspace,
+                                         int64_t rows, int C, int64_t rows_per_sample, dgtd_dtype dt, int* nblocks, dgtd_stream st);
+int dgtd_gelu_bias_bwd_partial(const void* g, const void* pre, void* dpre, void* workspace, int64_t rows, int C, dgtd_dtype dt,
+                               int* nblocks, dgtd_stream st);
+int dgtd_colsum_partial(const void* x, void* workspace, int64_t rows, int C, dgtd_dtype dt, int* nblocks, dgtd_stream st);
 /* out [C] (dtype out_dt, fp32 accumulation) = column sums of x [rows, C]: the bias gradient of nn.Linear
  * (cod.py:829,832,872-875,1097,1099), written in the dtype of the bias it belongs to.                                   */
 int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt,
