@@ -505,8 +505,11 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
     const int kgroups = (int)cdiv(Nkv, KGROUP);
     DGTD_REQUIRE((int64_t)heads * kgroups <= 65535, "sra_attn_bwd: heads*kgroups too large for the grid");
     // 512 workgroups = two waves per SIMD: 75 -> 63 us at stage 1 (B=8, N=16384); 1024 loses again to the extra atomic flushes (81 us)
-    static const int64_t wg_target = getenv("DGTD_DKDV_WGS") ? atol(getenv("DGTD_DKDV_WGS")) : 512;
-    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(wg_target, (int64_t)B * heads * kgroups)));
+    static const int64_t wg_env = getenv("DGTD_DKDV_WGS") ? atol(getenv("DGTD_DKDV_WGS")) : 0;
+    const int64_t cols = (int64_t)B * heads * kgroups;
+    // (measured per stage of config 2: 512 helps the long-query stages 1-2, costs 8-9 us at stages 3-4 where it only adds flushes)
+    const int64_t wg_target = wg_env ? wg_env : (cols <= 32 ? 512 : 256);
+    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(wg_target, cols)));
     const int qch = (int)cdiv(qtiles, nq);
     const int nqc = (int)cdiv(qtiles, qch);
     DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL(sra_bwd_dkdv_bf16<T_>, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const T_*)q, (const T_*)kv,
