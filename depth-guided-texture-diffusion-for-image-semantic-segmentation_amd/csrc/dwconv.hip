@@ -298,13 +298,15 @@ static int bww_ysplit(int B, int H, int W, int C, int TX, int K) {
 }
 
 template <typename T, int K, int TX>
-int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, hipStream_t s) {
+int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* workspace, int B, int H, int W, int C, hipStream_t s,
+               int* nblocks = nullptr) {
   DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight: C=%d must be a multiple of 128", C);
   const int ncb = C / 128, ys = bww_ysplit(B, H, W, C, TX, K);
   const int gx = B * (int)cdiv(W, TX) * ys;
   hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, TX>), dim3(gx, ncb), dim3(K * 64), 0, s, (const T*)x, (const T*)du, (float*)workspace,
                      has_bias, B, H, W, C, ys);
   DGTD_CHECK_LAUNCH("dwconv_bwd_weight");
+  if (nblocks) { *nblocks = gx; return 0; }
   const int ncols = (K * K + 1) * C;
   hipLaunchKernelGGL(dwconv_bww_reduce_kernel, dim3((int)cdiv(ncols, 32)), dim3(256), 0, s, (const float*)workspace, grads, gx, ncols);
   DGTD_CHECK_LAUNCH("dwconv_bww_reduce");
@@ -358,6 +360,22 @@ extern "C" int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grad
   if (dt == DGTD_F32) return K == 7 ? bww_launch<float, 7, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st)
                                     : bww_launch<float, 3, 8>(x, du, grads, has_bias, workspace, B, H, W, C, st);
   DGTD_FAIL(2, "dwconv_bwd_weight: bad dtype %d", (int)dt);
+}
+
+extern "C" int dgtd_dwconv_bwd_weight_partial(const void* x, const void* du, int has_bias, void* workspace, int B, int H, int W, int C, int K,
+                                              dgtd_dtype dt, int* nblocks, dgtd_stream s) {
+  DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && nblocks, "dwconv_bwd_weight_partial: bad sizes");
+  DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight_partial: K=%d (only 3 and 7 are on the path)", K);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "dwconv_bwd_weight_partial: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight_partial: C=%d must be a multiple of 128", C);
+  DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * B * H * W * C, "dgtd_dwconv_bwd_weight[k%d,%dx%dx%d]", K, H, W, C);
+  hipStream_t st = (hipStream_t)s;
+  if (dt == DGTD_BF16) return K == 7 ? bww_launch<bf16_t, 7, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks)
+                                     : bww_launch<bf16_t, 3, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks);
+  if (dt == DGTD_F16) return K == 7 ? bww_launch<f16_t, 7, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks)
+                                    : bww_launch<f16_t, 3, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks);
+  return K == 7 ? bww_launch<float, 7, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks)
+                : bww_launch<float, 3, 8>(x, du, nullptr, has_bias, workspace, B, H, W, C, st, nblocks);
 }
 
 extern "C" int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, int C, int K, dgtd_dtype wdt, dgtd_stream s) {

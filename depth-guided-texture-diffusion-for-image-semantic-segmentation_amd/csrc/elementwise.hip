@@ -97,15 +97,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, co
 // One workgroup = 32 columns x 8 row groups of ONE entry (a narrow tile: the partial buffers are small and the work latency-bound);
 // row group g sums rows g, g+8, ... with 8 loads in flight, the groups meet in LDS.  Fixed summation order.  The entry table travels
 // by value in the kernel arguments (hipGraph-safe).
-constexpr int MR_MAX = 56;
+constexpr int MR_MAX = 48;
 struct MrTable {
   const float* ws[MR_MAX];
   float* outA[MR_MAX];
   void* outB[MR_MAX];
-  int nblocks[MR_MAX], ncols[MR_MAX], nA[MR_MAX], dtB[MR_MAX];
+  void* outC[MR_MAX];
+  int nblocks[MR_MAX], ncols[MR_MAX], nA[MR_MAX], dtB[MR_MAX], tr_rows[MR_MAX], tr_cols[MR_MAX];
   int first_tile[MR_MAX + 1];
   int count;
 };
+
+__device__ __forceinline__ void mr_store(void* out, int dt, int i, float v) {
+  if (dt == DGTD_BF16) ((bf16_t*)out)[i] = (bf16_t)v;
+  else if (dt == DGTD_F16) ((f16_t*)out)[i] = (f16_t)v;
+  else ((float*)out)[i] = v;
+}
 
 __global__ __launch_bounds__(256) void multi_reduce_kernel(MrTable t) {
   __shared__ float part[8][32];
@@ -116,7 +123,8 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(MrTable t) {
   const int lane = threadIdx.x & 31, rgp = threadIdx.x >> 5;
   const int col = (tile - t.first_tile[e]) * 32 + lane;
   const int ncols = t.ncols[e], nblocks = t.nblocks[e], nA = t.nA[e];
-  const bool live = col < ncols && (col >= nA || t.outA[e] != nullptr);
+  const int trn = t.tr_rows[e] * t.tr_cols[e];          // columns [nA, nA + trn) are the transposed block, the rest goes to outC
+  const bool live = col < ncols && (col >= nA || t.outA[e] != nullptr) && (trn == 0 || col < nA + trn || t.outC[e] != nullptr);
   float s0 = 0.f, s1 = 0.f;
   if (live) {
     const float* p = t.ws[e] + col;
@@ -137,9 +145,9 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(MrTable t) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v += part[k][lane];
     if (col < nA) t.outA[e][col] = v;
-    else if (t.dtB[e] == DGTD_BF16) ((bf16_t*)t.outB[e])[col - nA] = (bf16_t)v;
-    else if (t.dtB[e] == DGTD_F16) ((f16_t*)t.outB[e])[col - nA] = (f16_t)v;
-    else ((float*)t.outB[e])[col - nA] = v;
+    else if (trn == 0) mr_store(t.outB[e], t.dtB[e], col - nA, v);
+    else if (col - nA < trn) { const int j = col - nA, tt = j / t.tr_cols[e], c = j % t.tr_cols[e]; mr_store(t.outB[e], t.dtB[e], c * t.tr_rows[e] + tt, v); }
+    else mr_store(t.outC[e], t.dtB[e], col - nA - trn, v);
   }
 }
 
@@ -165,7 +173,7 @@ int colsum_launch(const void* g, const void* y, const float* s, const float* gam
   if (nblocks) { *nblocks = gx; return 0; }
   if (MODE != 2) {
     const dgtd_reduce_entry e{(const float*)ws, gx, C, out_dt == DGTD_F32 ? (float*)out : nullptr, out_dt == DGTD_F32 ? C : 0,
-                              out_dt == DGTD_F32 ? nullptr : out, out_dt};
+                              out_dt == DGTD_F32 ? nullptr : out, out_dt, 0, 0, nullptr};
     return dgtd_multi_reduce_impl(&e, 1, st);
   }
   return 0;
@@ -251,7 +259,7 @@ int colsum2_launch(const void* g, const void* y, const float* s, const float* ga
   DGTD_CHECK_LAUNCH(who);
   if (nblocks) { *nblocks = gx; return 0; }
   // columns [0, C) = dgamma partials (garbage when the kernel had no gamma: then outA is NULL and they are skipped), [C, 2C) = dbias
-  const dgtd_reduce_entry e{(const float*)ws, gx, 2 * C, outA, C, outB, outB_bf16};
+  const dgtd_reduce_entry e{(const float*)ws, gx, 2 * C, outA, C, outB, outB_bf16, 0, 0, nullptr};
   return dgtd_multi_reduce_impl(&e, 1, st);
 }
 
@@ -266,7 +274,9 @@ int dgtd_multi_reduce_impl(const dgtd_reduce_entry* entries, int n, hipStream_t 
     for (int i = 0; i < m; ++i) {
       const dgtd_reduce_entry& e = entries[b0 + i];
       DGTD_REQUIRE(e.ws && e.nblocks > 0 && e.ncols > 0 && e.nA >= 0 && e.nA <= e.ncols && (e.nA == e.ncols || e.outB), "multi_reduce: bad entry %d", b0 + i);
-      t.ws[i] = e.ws; t.outA[i] = e.outA; t.outB[i] = e.outB; t.nblocks[i] = e.nblocks; t.ncols[i] = e.ncols; t.nA[i] = e.nA; t.dtB[i] = e.dtB;
+      DGTD_REQUIRE(e.tr_rows >= 0 && e.tr_cols >= 0 && e.nA + e.tr_rows * e.tr_cols <= e.ncols, "multi_reduce: bad transpose block in entry %d", b0 + i);
+      t.ws[i] = e.ws; t.outA[i] = e.outA; t.outB[i] = e.outB; t.outC[i] = e.outC; t.nblocks[i] = e.nblocks; t.ncols[i] = e.ncols; t.nA[i] = e.nA;
+      t.dtB[i] = e.dtB; t.tr_rows[i] = e.tr_rows; t.tr_cols[i] = e.tr_cols;
       t.first_tile[i] = tiles;
       tiles += (int)cdiv(e.ncols, 32);
     }

@@ -249,7 +249,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float
 #undef LN_BWD
   DGTD_CHECK_LAUNCH("layernorm_bwd");
   if (nblocks) { *nblocks = grid; return 0; }
-  const dgtd_reduce_entry e{(const float*)ws, grid, 2 * C, dgamma, C, dbeta, DGTD_F32};     // ws [grid][2C] = { dgamma | dbeta } partial rows
+  const dgtd_reduce_entry e{(const float*)ws, grid, 2 * C, dgamma, C, dbeta, DGTD_F32, 0, 0, nullptr};     // ws [grid][2C] = { dgamma | dbeta } partial rows
   return dgtd_multi_reduce_impl(&e, 1, s);
 }
 

@@ -51,9 +51,10 @@ static std::vector<PendingReduce> g_pending;
 static std::atomic<bool> g_defer{false};
 
 inline bool deferring() { return g_defer.load(std::memory_order_relaxed); }
-inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, void* outB, dgtd_dtype dtB) {
+inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, void* outB, dgtd_dtype dtB, int tr_rows = 0, int tr_cols = 0,
+                 void* outC = nullptr) {
   std::lock_guard<std::mutex> lk(g_pending_mu);
-  g_pending.push_back(PendingReduce{dgtd_reduce_entry{ws.data_ptr<float>(), nblocks, ncols, outA, nA, outB, (int32_t)dtB}, ws});
+  g_pending.push_back(PendingReduce{dgtd_reduce_entry{ws.data_ptr<float>(), nblocks, ncols, outA, nA, outB, (int32_t)dtB, tr_rows, tr_cols, outC}, ws});
 }
 void flush_deferred() {
   std::vector<PendingReduce> todo;
@@ -196,6 +197,24 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
 };
 
 // ------------------------------------------------------------------------------------------------ depthwise conv (NHWC)
+// weight / bias gradient of a depthwise convolution: first stage into per-workgroup partial rows { dw_t | db }, then ONE multi-reduce
+// entry that also transposes into the Conv2d layout and converts to the parameters' dtype (was: reduce + unpack, two launches) - parked
+// with the other column reductions of the backward pass when the reducer has switched deferral on.
+inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias, int64_t C, int64_t K, Tensor& dw, Tensor& db) {
+  const int64_t KK = K * K;
+  Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K) / 4}, x.options().dtype(at::kFloat));
+  int nb = 0;
+  check(dgtd_dwconv_bwd_weight_partial(x.data_ptr(), du.data_ptr(), has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
+                                       (int)C, (int)K, code(x), &nb, stream()), "dgtd_dwconv_bwd_weight_partial");
+  if (deferring()) {
+    park(ws, nb, (int)((KK + 1) * C), nullptr, 0, dw.data_ptr(), code(dw), (int)KK, (int)C, has_bias ? db.data_ptr() : nullptr);
+  } else {
+    const dgtd_reduce_entry e{ws.data_ptr<float>(), nb, (int32_t)((KK + 1) * C), nullptr, 0, dw.data_ptr(), (int32_t)code(dw), (int32_t)KK, (int32_t)C,
+                              has_bias ? db.data_ptr() : nullptr};
+    check(dgtd_multi_reduce(&e, 1, stream()), "dgtd_multi_reduce");
+  }
+}
+
 struct DwConvFn : public torch::autograd::Function<DwConvFn> {
   static Tensor launch(const Tensor& x, const float* wt, const float* bias, const Tensor* aux, int mode, int K) {
     Tensor y = at::empty_like(x);
@@ -235,15 +254,9 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     const float* bias = has_bias ? base + 2 * KK * C : nullptr;
     Tensor du = gelu ? launch(x, base, bias, &dy, 2, (int)K) : dy;          // through the GELU: recompute the pre-activation
     Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);     // bwd-data = same kernel, flipped filter
-    Tensor grads = at::empty({(KK + 1) * C}, x.options().dtype(at::kFloat));
-    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K)}, x.options().dtype(at::kByte));
-    float* gb = grads.data_ptr<float>();
-    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1),
-                                 (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
-    check(dgtd_dwconv_unpack_grads(gb, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int)C, (int)K, code(dw), stream()),
-          "dgtd_dwconv_unpack_grads");
+    dwconv_weight_grads(x, du, has_bias, C, K, dw, db);
     return {dx, dw, db, undefined()};
   }
 };
@@ -282,15 +295,9 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     if (du.scalar_type() != x.scalar_type()) du = du.to(x.scalar_type());
     const float* base = packed.data_ptr<float>();
     Tensor dx = skip.defined() ? DwConvFn::launch(du, base + KK * C, nullptr, &skip, 3, (int)K) : DwConvFn::launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);
-    Tensor grads = at::empty({(KK + 1) * C}, x.options().dtype(at::kFloat));
-    Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K)}, x.options().dtype(at::kByte));
-    float* gb = grads.data_ptr<float>();
-    check(dgtd_dwconv_bwd_weight(x.data_ptr(), du.data_ptr(), gb, has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1),
-                                 (int)x.size(2), (int)C, (int)K, code(x), stream()), "dgtd_dwconv_bwd_weight");
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
-    check(dgtd_dwconv_unpack_grads(gb, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int)C, (int)K, code(dw), stream()),
-          "dgtd_dwconv_unpack_grads");
+    dwconv_weight_grads(x, du, has_bias, C, K, dw, db);
     return {dx, dw, db};
   }
 };

@@ -99,6 +99,10 @@ int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int 
 int64_t dgtd_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int K);
 int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_bias, void* workspace,
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
+/* First stage only: workspace receives [*nblocks][(K*K + 1) * C] = { dw_t | db } partial rows; finish with a dgtd_multi_reduce entry
+ * with tr_rows = K*K, tr_cols = C (writes dw [C,1,K,K] and db [C] in the parameters' dtype: no separate unpack launch).          */
+int dgtd_dwconv_bwd_weight_partial(const void* x, const void* du, int has_bias, void* workspace, int B, int H, int W, int C, int K,
+                                   dgtd_dtype dt, int* nblocks, dgtd_stream s);
 
 /* ---- Second stage of the two-stage column reductions, for MANY reductions in one launch --------------------------------------
  * The backward kernels below that also produce a per-column sum (LayerNorm dgamma/dbeta, the bias gradient of every nn.Linear, the
@@ -106,6 +110,9 @@ int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_
  * run that pass themselves; their `_partial` siblings stop after the first stage and report `nblocks`, so that a caller can run the
  * second stage of a whole backward pass (≈ 290 reductions per training step) in a handful of launches with dgtd_multi_reduce.
  * One entry: out columns [0, nA) of the row sum go to outA as fp32 (skipped when outA is NULL), columns [nA, ncols) to outB in dtB.
+ * tr_rows > 0 (depthwise-conv weight gradients): the outB columns are a [tr_rows][tr_cols] matrix (tap-major partials { dw_t }) that
+ * is written TRANSPOSED, outB[c * tr_rows + t] (= Conv2d weight layout [C,1,K,K]); the columns after it ({ db }) go to outC in dtB
+ * (skipped when outC is NULL).
  * Fixed summation order (deterministic), identical to what the plain entry points produce.  entries: HOST array.                  */
 typedef struct {
   const float* ws;   /* partial rows [nblocks][ncols], fp32 */
@@ -114,6 +121,8 @@ typedef struct {
   int32_t nA;
   void* outB;        /* [ncols - nA] in dtB, or NULL when nA == ncols */
   int32_t dtB;       /* dgtd_dtype */
+  int32_t tr_rows, tr_cols;   /* 0, 0 = no transpose */
+  void* outC;
 } dgtd_reduce_entry;
 int dgtd_multi_reduce(const dgtd_reduce_entry* entries, int n, dgtd_stream s);
 
