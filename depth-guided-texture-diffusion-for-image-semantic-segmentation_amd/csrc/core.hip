@@ -35,14 +35,14 @@ DgtdProfScope::DgtdProfScope(hipStream_t st_, int bound_, double amount_, const 
   vsnprintf(key, sizeof(key), fmt, ap);
   va_end(ap);
   if (hipEventCreate(&a) != hipSuccess) return;
-  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
-  hipEventRecord(a, st);
+  if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+  (void)hipEventRecord(a, st);
   on = true;
 }
 
 DgtdProfScope::~DgtdProfScope() {
   if (!on) return;
-  hipEventRecord(b, st);
+  (void)hipEventRecord(b, st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_recs.push_back(ProfRec{key, a, b, bound, amount});
 }
@@ -50,7 +50,7 @@ DgtdProfScope::~DgtdProfScope() {
 extern "C" int dgtd_profile_enable(int on) {
   if (on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& r : g_prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof_recs.clear();
   }
   g_prof_on.store(on ? 1 : 0);

@@ -247,6 +247,92 @@ __global__ __launch_bounds__(K * 64) void dwconv_bwd_weight_kernel(const T* __re
   if (ky == P) { f32x2 v; v[0] = has_bias ? accb[0] : 0.f; v[1] = has_bias ? accb[1] : 0.f; *reinterpret_cast<f32x2*>(wsb + (size_t)(K * K) * C) = v; }
 }
 
+// The same weight gradient for up to BW_MAX same-shaped layers in ONE launch (deferred weight-gradient phase: a layer's (input,
+// output-gradient) pair stays in HBM until the backward pass is over, then every depthwise layer of one shape is served together).
+// One layer at [8,32,32,512] is 16 MB: 1024 workgroups of 4 rows each, 4x its bytes in partial sums, and a launch that is over
+// before the chip is busy.  27 such layers are 453 MB: here a workgroup (K waves = K filter rows, as above) walks a whole row range
+// of one image x 128 channels with the accumulators in registers (x fastest, so the column halo re-reads hit L1/L2 at once) and
+// writes ONE partial: partial traffic drops from 4x the input to a few per cent, and the launch is a plain HBM stream.
+constexpr int BW_MAX = 32;
+struct BwwTable { const void* x[BW_MAX]; const void* du[BW_MAX]; };
+
+template <typename T, int K, int TX>
+__global__ __launch_bounds__(K * 64) void dwconv_bww_batched_kernel(BwwTable tab, float* __restrict__ ws, int has_bias,
+                                                                    int B, int H, int W, int C, int ysplit) {
+  typedef typename Pair<T>::type PT;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int P = K / 2;
+  // The kernel is VALU-bound (56 packed FMAs + 44 conversions per 22 loads), so everything that can be wave-uniform is kept on the
+  // scalar unit: the filter row (readfirstlane), the row base pointers and the boundary tests; the only per-lane address part is
+  // the channel offset, which lets the loads take the scalar-base + VGPR-offset form.
+  const int lane = threadIdx.x & 63, ky = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane2 = lane * 2;
+  const int ypart = blockIdx.x % ysplit, b = (blockIdx.x / ysplit) % B, z = blockIdx.x / (ysplit * B);
+  const size_t img = (size_t)b * H * W * C + (size_t)blockIdx.y * 128;
+  const T* __restrict__ x = (const T*)tab.x[z] + img;
+  const T* __restrict__ du = (const T*)tab.du[z] + img;
+  const int rows_per = (H + ysplit - 1) / ysplit;
+  const int y_begin = ypart * rows_per, y_end = min(H, y_begin + rows_per);
+  f32x2 acc[K], accb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < K; ++t) acc[t] = f32x2{0.f, 0.f};
+  const int ya = max(y_begin, P - ky), yb = min(y_end, H + P - ky);
+  const int XB = (W + TX - 1) / TX;
+  const int nit = max(0, yb - ya) * XB;
+  int fy = ya, fx = 0;                                            // coordinates of the NEXT fetch (x fastest)
+  auto fetch = [&](PT* gr, PT* ir) {
+    const T* grow = du + ((size_t)fy * W + fx) * C;
+    const T* row = x + ((ptrdiff_t)(fy + ky - P) * W + (fx - P)) * (ptrdiff_t)C;
+    if (fx - P >= 0 && fx + TX + P <= W) {                        // straight-line loads
+#pragma unroll
+      for (int t = 0; t < TX; ++t) gr[t] = *reinterpret_cast<const PT*>(grow + t * C + lane2);
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) ir[i] = *reinterpret_cast<const PT*>(row + i * C + lane2);
+    } else {
+      PT zero; zero[0] = (T)0.f; zero[1] = (T)0.f;
+#pragma unroll
+      for (int t = 0; t < TX; ++t) gr[t] = (fx + t < W) ? *reinterpret_cast<const PT*>(grow + t * C + lane2) : zero;
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) {
+        const int xx = fx + i - P;
+        ir[i] = (xx >= 0 && xx < W) ? *reinterpret_cast<const PT*>(row + i * C + lane2) : zero;
+      }
+    }
+    fx += TX;
+    if (fx >= W) { fx = 0; ++fy; }
+  };
+  auto compute = [&](const PT* gr, const PT* ir) {
+    f32x2 g[TX], in[TX + K - 1];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) g[t] = f32x2{(float)gr[t][0], (float)gr[t][1]};
+#pragma unroll
+    for (int i = 0; i < TX + K - 1; ++i) in[i] = f32x2{(float)ir[i][0], (float)ir[i][1]};
+    if (ky == P) {
+#pragma unroll
+      for (int t = 0; t < TX; ++t) accb += g[t];
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+      for (int t = 0; t < TX; ++t) acc[kx] = __builtin_elementwise_fma(g[t], in[t + kx], acc[kx]);
+  };
+  // two register sets, alternating roles: the loads of tile it+1 are in flight while tile it is consumed, without register copies
+  PT gA[TX], iA[TX + K - 1], gB[TX], iB[TX + K - 1];
+  if (nit > 0) fetch(gA, iA);
+  for (int it = 0; it < nit; it += 2) {
+    if (it + 1 < nit) fetch(gB, iB);
+    compute(gA, iA);
+    if (it + 1 >= nit) break;
+    if (it + 2 < nit) fetch(gA, iA);
+    compute(gB, iB);
+  }
+  // ws[z][b * ysplit + ypart][K*K + 1][C]
+  float* wsb = ws + (size_t)blockIdx.x * (K * K + 1) * C + blockIdx.y * 128 + lane2;
+#pragma unroll
+  for (int t = 0; t < K; ++t) *reinterpret_cast<f32x2*>(wsb + (size_t)(ky * K + t) * C) = acc[t];
+  if (ky == P) *reinterpret_cast<f32x2*>(wsb + (size_t)(K * K) * C) = has_bias ? accb : f32x2{0.f, 0.f};
+}
+
 // weights [C, K*K] (Conv2d layout, dtype T) + bias [C] -> packed fp32 [ wt (K*K x C) | wt spatially flipped | bias ]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ w, const T* __restrict__ bias,
@@ -313,7 +399,55 @@ int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* 
   return 0;
 }
 
+// row ranges per image so that the batched launch has >= ~6 workgroups per CU (each K waves), never fewer than 4 rows per range
+static int bww_batched_ysplit(int n, int B, int H, int C) {
+  static const int64_t target = getenv("DGTD_BWW_BATCHED_WGS") ? atol(getenv("DGTD_BWW_BATCHED_WGS")) : 1536;
+  int ys = 1;
+  while ((int64_t)n * B * (C / 128) * ys < target && H / (ys * 2) >= 4) ys *= 2;
+  return ys;
+}
+
+template <typename T, int K, int TX>
+int bww_batched_launch(const void* const* x, const void* const* du, int n, int has_bias, float* ws, int B, int H, int W, int C, int ys,
+                       hipStream_t s) {
+  for (int z0 = 0; z0 < n; z0 += BW_MAX) {
+    const int m = std::min(BW_MAX, n - z0);
+    BwwTable tab;
+    for (int i = 0; i < m; ++i) { tab.x[i] = x[z0 + i]; tab.du[i] = du[z0 + i]; }
+    for (int i = m; i < BW_MAX; ++i) { tab.x[i] = nullptr; tab.du[i] = nullptr; }
+    hipLaunchKernelGGL((dwconv_bww_batched_kernel<T, K, TX>), dim3(m * B * ys, C / 128), dim3(K * 64), 0, s, tab,
+                       ws + (size_t)z0 * B * ys * (K * K + 1) * C, has_bias, B, H, W, C, ys);
+    DGTD_CHECK_LAUNCH("dwconv_bww_batched");
+  }
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int dgtd_dwconv_bwd_weight_batched_blocks(int n, int B, int H, int W, int C, int K) {
+  (void)W; (void)K;
+  return C % 128 == 0 && n > 0 ? B * bww_batched_ysplit(n, B, H, C) : 0;
+}
+
+extern "C" int dgtd_dwconv_bwd_weight_batched(const void* const* x, const void* const* du, int n, int has_bias, void* workspace, int B, int H,
+                                              int W, int C, int K, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(n > 0 && x && du && workspace, "dwconv_bwd_weight_batched: no layers");
+  DGTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd_weight_batched: bad sizes");
+  DGTD_REQUIRE(K == 3 || K == 7, "dwconv_bwd_weight_batched: K=%d (only 3 and 7 are on the path)", K);
+  DGTD_REQUIRE(DGTD_IS_HALF(dt) || dt == DGTD_F32, "dwconv_bwd_weight_batched: bad dtype %d", (int)dt);
+  DGTD_REQUIRE(C % 128 == 0, "dwconv_bwd_weight_batched: C=%d must be a multiple of 128", C);
+  for (int i = 0; i < n; ++i) DGTD_REQUIRE(x[i] && du[i], "dwconv_bwd_weight_batched: null tensor in layer %d", i);
+  DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * n * B * H * W * C, "dgtd_dwconv_bwd_weight_batched[n%d,k%d,%dx%dx%d]", n, K, H, W, C);
+  hipStream_t st = (hipStream_t)s;
+  const int ys = bww_batched_ysplit(n, B, H, C);
+  float* ws = (float*)workspace;
+  if (dt == DGTD_BF16) return K == 7 ? bww_batched_launch<bf16_t, 7, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st)
+                                     : bww_batched_launch<bf16_t, 3, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st);
+  if (dt == DGTD_F16) return K == 7 ? bww_batched_launch<f16_t, 7, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st)
+                                    : bww_batched_launch<f16_t, 3, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st);
+  return K == 7 ? bww_batched_launch<float, 7, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st)
+                : bww_batched_launch<float, 3, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st);
+}
 
 extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const void* aux, void* y, int B, int H, int W,
                                int C, int K, int mode, dgtd_dtype dt, dgtd_stream s) {

@@ -56,22 +56,62 @@ inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, 
   std::lock_guard<std::mutex> lk(g_pending_mu);
   g_pending.push_back(PendingReduce{dgtd_reduce_entry{ws.data_ptr<float>(), nblocks, ncols, outA, nA, outB, (int32_t)dtB, tr_rows, tr_cols, outC}, ws});
 }
+// Deferred WEIGHT GRADIENTS of the depthwise convolutions: the node only remembers its (input, output-gradient) pair; at the flush
+// every parked layer of one shape is served by ONE dgtd_dwconv_bwd_weight_batched launch (27 ConvNeXt stage-3 layers at config 2:
+// 453 MB streamed once, instead of 27 launches of 16 MB that are over before the chip is busy and write 4x their input in partials).
+struct PendingDw { Tensor x, du; void* dw; void* db; int32_t dw_dt; bool has_bias; int B, H, W, C, K; };
+static std::vector<PendingDw> g_pending_dw;
+
+inline void park_dw(const Tensor& x, const Tensor& du, Tensor& dw, Tensor& db, bool has_bias, int C, int K) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_pending_dw.push_back(PendingDw{x, du, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int32_t)code(dw), has_bias, (int)x.size(0), (int)x.size(1),
+                                   (int)x.size(2), C, K});
+}
 void flush_deferred() {
   std::vector<PendingReduce> todo;
+  std::vector<PendingDw> dws;
   {
     std::lock_guard<std::mutex> lk(g_pending_mu);
     todo.swap(g_pending);
+    dws.swap(g_pending_dw);
   }
-  if (todo.empty()) return;
+  if (todo.empty() && dws.empty()) return;
   std::vector<dgtd_reduce_entry> es;
-  es.reserve(todo.size());
+  es.reserve(todo.size() + dws.size());
   for (auto& p : todo) es.push_back(p.e);
+  std::vector<Tensor> keep;
+  std::vector<bool> done(dws.size(), false);
+  for (size_t i = 0; i < dws.size(); ++i) {
+    if (done[i]) continue;
+    const PendingDw& a = dws[i];
+    std::vector<size_t> grp;
+    for (size_t j = i; j < dws.size(); ++j) {
+      const PendingDw& b = dws[j];
+      if (!done[j] && b.B == a.B && b.H == a.H && b.W == a.W && b.C == a.C && b.K == a.K && b.has_bias == a.has_bias &&
+          b.x.scalar_type() == a.x.scalar_type() && b.x.device() == a.x.device()) { grp.push_back(j); done[j] = true; }
+    }
+    const int n = (int)grp.size(), KK = a.K * a.K;
+    const int blocks = dgtd_dwconv_bwd_weight_batched_blocks(n, a.B, a.H, a.W, a.C, a.K);
+    const int64_t per = (int64_t)blocks * (KK + 1) * a.C;
+    Tensor ws = at::empty({(int64_t)n * per}, a.x.options().dtype(at::kFloat));
+    std::vector<const void*> xs(n), dus(n);
+    for (int k = 0; k < n; ++k) { xs[k] = dws[grp[k]].x.data_ptr(); dus[k] = dws[grp[k]].du.data_ptr(); }
+    check(dgtd_dwconv_bwd_weight_batched(xs.data(), dus.data(), n, a.has_bias ? 1 : 0, ws.data_ptr(), a.B, a.H, a.W, a.C, a.K, code(a.x), stream()),
+          "dgtd_dwconv_bwd_weight_batched");
+    for (int k = 0; k < n; ++k) {
+      const PendingDw& d = dws[grp[k]];
+      es.push_back(dgtd_reduce_entry{ws.data_ptr<float>() + (int64_t)k * per, blocks, (int32_t)((KK + 1) * a.C), nullptr, 0, d.dw, d.dw_dt, (int32_t)KK,
+                                     (int32_t)a.C, d.db});
+    }
+    keep.push_back(ws);
+  }
   check(dgtd_multi_reduce(es.data(), (int)es.size(), stream()), "dgtd_multi_reduce");
 }
 void set_deferred(bool on) {
   if (on) {   // entries left over from a backward that was never flushed point at dead memory: drop them
     std::lock_guard<std::mutex> lk(g_pending_mu);
     g_pending.clear();
+    g_pending_dw.clear();
   } else {
     flush_deferred();
   }
@@ -79,7 +119,7 @@ void set_deferred(bool on) {
 }
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
-  return (int64_t)g_pending.size();
+  return (int64_t)(g_pending.size() + g_pending_dw.size());
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -202,6 +242,8 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
 // with the other column reductions of the backward pass when the reducer has switched deferral on.
 inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias, int64_t C, int64_t K, Tensor& dw, Tensor& db) {
   const int64_t KK = K * K;
+  static const bool batch_dw = [] { const char* e = std::getenv("DGTD_DEFER_DWCONV"); return !e || std::atoi(e) != 0; }();
+  if (deferring() && batch_dw) { park_dw(x, du, dw, db, has_bias, (int)C, (int)K); return; }
   Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K) / 4}, x.options().dtype(at::kFloat));
   int nb = 0;
   check(dgtd_dwconv_bwd_weight_partial(x.data_ptr(), du.data_ptr(), has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1), (int)x.size(2),

@@ -101,6 +101,12 @@ int dgtd_dwconv_bwd_weight(const void* x, const void* du, float* grads, int has_
                            int B, int H, int W, int C, int K, dgtd_dtype dt, dgtd_stream s);
 /* First stage only: workspace receives [*nblocks][(K*K + 1) * C] = { dw_t | db } partial rows; finish with a dgtd_multi_reduce entry
  * with tr_rows = K*K, tr_cols = C (writes dw [C,1,K,K] and db [C] in the parameters' dtype: no separate unpack launch).          */
+/* Deferred weight-gradient phase: the same first stage for n same-shaped layers in ONE launch.  x, du: HOST arrays of n device
+ * pointers.  workspace receives [n][blocks][(K*K + 1) * C] partial rows, blocks = dgtd_dwconv_bwd_weight_batched_blocks(n, ...)
+ * (fp32; size n * blocks * (K*K+1) * C * 4 bytes); finish each layer with a transposing dgtd_multi_reduce entry as above.        */
+int dgtd_dwconv_bwd_weight_batched_blocks(int n, int B, int H, int W, int C, int K);
+int dgtd_dwconv_bwd_weight_batched(const void* const* x, const void* const* du, int n, int has_bias, void* workspace, int B, int H, int W,
+                                   int C, int K, dgtd_dtype dt, dgtd_stream s);
 int dgtd_dwconv_bwd_weight_partial(const void* x, const void* du, int has_bias, void* workspace, int B, int H, int W, int C, int K,
                                    dgtd_dtype dt, int* nblocks, dgtd_stream s);
 

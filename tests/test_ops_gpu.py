@@ -493,6 +493,48 @@ def test_dwconv_benchmarked_shapes_vs_fp32_torch(dgtd, K, gelu, B, H, W, C, half
     torch.testing.assert_close(hw.float(), gw, atol=3e-2 * math.sqrt(n), rtol=5e-2)
 
 
+DWB = [(7, 5, 8, 32, 32, 512), (7, 3, 2, 20, 12, 256), (3, 4, 2, 16, 16, 1024), (7, 35, 1, 9, 8, 128)]
+
+
+@pytest.mark.parametrize("K,L,B,H,W,C", DWB, ids=[f"k{s[0]}_n{s[1]}_{s[2]}x{s[3]}x{s[4]}x{s[5]}" for s in DWB])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+def test_dwconv_weight_gradients_deferred_and_batched(dgtd, K, L, B, H, W, C, dtype):
+    """Deferred weight-gradient phase: with deferral on, the depthwise nodes only park their (input, output-gradient) pairs; one
+    dgtd_dwconv_bwd_weight_batched launch per shape at the flush (n = 35 crosses the 32-entry table) + one transposing multi-reduce
+    must give every layer's weight / bias gradient, against fp32 F.conv2d.  A second shape parked in between keeps its own group."""
+    nat = dgtd.ops._native.ops()
+    if nat is None:
+        pytest.skip("deferral lives in the C++ binding layer")
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    layers = []
+    for i in range(L):
+        x = _rand(B, H, W, C, seed=10 + i, dtype=dtype)
+        w = (_rand(C, 1, K, K, seed=50 + i) / K).to(dtype).requires_grad_()
+        b = (0.1 * _rand(C, seed=90 + i)).to(dtype).requires_grad_()
+        g = _rand(B, H, W, C, seed=130 + i, dtype=dtype)
+        layers.append((x, w, b, g))
+    other = (_rand(2, 8, 8, 128, seed=3, dtype=dtype), (_rand(128, 1, 3, 3, seed=4) / 3).to(dtype).requires_grad_(), None, _rand(2, 8, 8, 128, seed=5, dtype=dtype))
+    nat.set_deferred(True)
+    try:
+        got = []
+        for i, (x, w, b, g) in enumerate(layers + [other]):
+            y = dgtd.ops.dwconv_nhwc(x, w, b, False)
+            got.append(torch.autograd.grad(y, (w, b) if b is not None else (w,), g))
+        assert nat.pending_reductions() == L + 1
+    finally:
+        nat.set_deferred(False)                                   # flushes
+    assert nat.pending_reductions() == 0
+    for (x, w, b, g), gr in zip(layers + [other], got):
+        wr = w.detach().float().requires_grad_()
+        br = b.detach().float().requires_grad_() if b is not None else None
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wr, br, padding=w.shape[-1] // 2, groups=w.shape[0]).permute(0, 2, 3, 1)
+        rw = torch.autograd.grad(ref, (wr, br) if b is not None else (wr,), g.float())
+        assert gr[0].dtype == dtype and gr[0].shape == w.shape
+        assert (gr[0].float() - rw[0]).norm() / rw[0].norm() < tol, "weight gradient"
+        if b is not None:
+            assert (gr[1].float() - rw[1]).norm() / rw[1].norm() < tol, "bias gradient"
+
+
 @pytest.mark.parametrize("scale", [2, 4, 8])
 @pytest.mark.parametrize("half", [torch.float32] + HALVES, ids=str)
 def test_prompt_tail_weight_gradient_with_channels_last_weights(dgtd, scale, half):

@@ -16,7 +16,7 @@ def category(n: str) -> str:
     if any(k in n for k in ("igemm", "naive_conv", "SubTensorOp", "batched_transpose", "Im2d", "Col2Im", "grouped_conv", "gridwise", "miopen")):
         return "library dense conv (MIOpen, incl. its layout transforms)"
     if any(k in n for k in ("dwconv", "ln_fwd", "ln_bwd", "sra_", "attn_delta", "diffus", "colsum", "scale_residual", "conv3x3", "bilinear_fwd_kernel", "bilinear_bwd_kernel",
-                            "prelu_", "ca_gate", "ca_apply", "pooled_sum", "loss_", "im2col", "col2im", "multi_copy", "ssim_", "found_inf", "preprocess", "resize_")):
+                            "prelu_", "ca_gate", "ca_apply", "pooled_sum", "loss_", "im2col", "col2im", "multi_copy", "multi_reduce", "ssim_", "found_inf", "preprocess", "resize_")):
         return "dgtd HIP kernels"
     if "reduce_kernel" in n:
         return "torch reductions"
