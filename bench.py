@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miou", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--all-kernels", default="", help="write EVERY kernel record of the instrumented pass (the JSON line keeps the top 12) to this file")
     return ap.parse_args()
 
 
@@ -280,6 +281,9 @@ def main():
         kernels.sort(key=lambda k: -k["ms_per_step"])
         # MFMA utilisation of the attention GEMMs (QK^T and AV, and their gradients), every stage: flops / device time / dense peak
         attention = [k for k in kernels if k["bound"] == "mfma"]
+        if args.all_kernels:
+            with open(args.all_kernels, "w") as f:
+                json.dump(kernels, f, indent=0)
         if kernels:
             roofline = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
             roofline["traffic_source"] = "offline rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE), HBM bytes per launch"

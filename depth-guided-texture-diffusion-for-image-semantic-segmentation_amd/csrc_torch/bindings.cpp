@@ -5,6 +5,9 @@
 #include <ATen/ATen.h>
 #include <atomic>
 #include <cstdlib>
+#include <algorithm>
+#include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 #include <c10/hip/HIPStream.h>
@@ -67,9 +70,118 @@ inline void park_dw(const Tensor& x, const Tensor& du, Tensor& dw, Tensor& db, b
   g_pending_dw.push_back(PendingDw{x, du, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int32_t)code(dw), has_bias, (int)x.size(0), (int)x.size(1),
                                    (int)x.size(2), C, K});
 }
+// Deferred WEIGHT GRADIENTS of the Linear layers of a run of identical blocks (ConvNeXt stage: 27 x pwconv1 / pwconv2 at config 2).
+// One layer's dW = dY^T X is a GEMM with a few hundred output tiles and an 8192-long reduction: the library needs split-K plus a
+// separate sum to fill the chip (36 us per layer).  The same GEMM batched over all layers of the stage fills it by itself
+// (tools/bench_grouped_gemm.cpp: 27 layers 344 us instead of 27 x 36).  hipBLASLt batches by STRIDE, so the operands of layer i must
+// sit at base + i * stride: while a block runs under an "arena hint" (group id, layer index, layer count; set by the module), the
+// producers of X (LayerNorm output, GELU output) and of dY (GELU' / layer-scale backward) write straight into slot i of a
+// per-(group, role) arena [count, rows, cols] instead of a fresh allocation - no copies - and the weight gradient itself is slot i
+// of a dW arena handed to autograd as the gradient tensor and filled at the flush (same contract as the parked reductions).
+enum ArenaRole { ROLE_X1 = 0, ROLE_X2 = 1, ROLE_DY1 = 2, ROLE_DY2 = 3, ROLE_DW1 = 4, ROLE_DW2 = 5 };
+struct Hint { int64_t group = -1; int idx = 0, count = 0; };
+static thread_local Hint t_hint;
+static std::map<std::pair<int64_t, int>, Tensor> g_arenas;
+
+void arena_hint(int64_t group, int64_t idx, int64_t count) { t_hint = Hint{count > 1 ? group : -1, (int)idx, (int)count}; }
+void arena_release(int64_t group) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  for (auto it = g_arenas.begin(); it != g_arenas.end();) it = it->first.first == group ? g_arenas.erase(it) : std::next(it);
+}
+int64_t arena_bytes() {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  int64_t n = 0;
+  for (auto& kv : g_arenas) n += kv.second.numel() * kv.second.element_size();
+  return n;
+}
+inline bool hinted(const Hint& h, at::ScalarType dt) { return h.group >= 0 && is16(dt) && deferring(); }
+inline Tensor arena_slot(const Hint& h, int role, at::IntArrayRef shape, const at::TensorOptions& opt) {
+  std::vector<int64_t> full{h.count};
+  full.insert(full.end(), shape.begin(), shape.end());
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  Tensor& a = g_arenas[{h.group, role}];
+  if (!a.defined() || a.sizes() != at::IntArrayRef(full) || a.scalar_type() != c10::typeMetaToScalarType(opt.dtype()) || a.device() != opt.device())
+    a = at::empty(full, opt);
+  // NOT a view: views share the arena's version counter, and every write into another slot would invalidate the tensors autograd
+  // saved from this one.  A blob over the slot's memory with its own storage object (the deleter keeps the arena alive).
+  Tensor keep = a;
+  int64_t n = 1;
+  for (auto d : shape) n *= d;
+  return at::from_blob((char*)a.data_ptr() + (int64_t)h.idx * n * a.element_size(), shape, [keep](void*) mutable { keep.reset(); }, opt);
+}
+inline bool in_arena(const Hint& h, int role, const Tensor& t) {       // is t exactly slot idx of this arena?
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  auto it = g_arenas.find({h.group, role});
+  return it != g_arenas.end() && it->second.defined() && it->second.size(0) == h.count && t.is_contiguous() &&
+         it->second.numel() / h.count == t.numel() && t.data_ptr() == (char*)it->second.data_ptr() + (int64_t)h.idx * t.numel() * t.element_size();
+}
+inline c10::IValue hint_iv(const Hint& h) { return std::vector<int64_t>{h.group, h.idx, h.count}; }
+inline Hint hint_of(const c10::IValue& v) { auto m = v.toIntVector(); return Hint{m[0], (int)m[1], (int)m[2]}; }
+
+struct PendingGemm { int64_t group; int which, idx; Tensor x, dy; void* dw; int64_t M, N, K; };   // dW [N,K] = dy[M,N]^T x[M,K]
+static std::vector<PendingGemm> g_pending_gemm;
+inline void park_gemm(const Hint& h, int which, const Tensor& x2, const Tensor& dy2, const Tensor& dw) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_pending_gemm.push_back(PendingGemm{h.group, which, h.idx, x2, dy2, dw.data_ptr(), dy2.size(0), dy2.size(1), x2.size(1)});
+}
+Tensor gemm_dw(const Tensor& dy2, const Tensor& x2);
+namespace dgemm_fwd { bool batched_dw(at::ScalarType dt, const void* dy, const void* x, void* dw, int64_t N, int64_t K, int64_t M, int batch, int64_t s_dy,
+                                      int64_t s_x, int64_t s_dw, const at::TensorOptions& o); }
+static void flush_gemms(std::vector<PendingGemm>& gs) {
+  std::sort(gs.begin(), gs.end(), [](const PendingGemm& a, const PendingGemm& b) {
+    return std::tie(a.group, a.which, a.idx) < std::tie(b.group, b.which, b.idx); });
+  for (size_t i = 0; i < gs.size();) {
+    // maximal run of consecutive layers of one (group, linear) whose operands are equally spaced: one strided-batched GEMM
+    const PendingGemm& a = gs[i];
+    const int64_t es = a.x.element_size();
+    size_t j = i + 1;
+    int64_t sx = 0, sdy = 0, sdw = 0;
+    while (j < gs.size() && gs[j].group == a.group && gs[j].which == a.which && gs[j].idx == gs[j - 1].idx + 1 && gs[j].M == a.M && gs[j].N == a.N &&
+           gs[j].K == a.K) {
+      const int64_t dx = ((char*)gs[j].x.data_ptr() - (char*)gs[j - 1].x.data_ptr()) / es, ddy = ((char*)gs[j].dy.data_ptr() - (char*)gs[j - 1].dy.data_ptr()) / es,
+                    ddw = ((char*)gs[j].dw - (char*)gs[j - 1].dw) / es;
+      if (j == i + 1) { sx = dx; sdy = ddy; sdw = ddw; }
+      else if (dx != sx || ddy != sdy || ddw != sdw) break;
+      ++j;
+    }
+    const int n = (int)(j - i);
+    // few layers with a long token dimension (3 blocks x 131072 tokens at stage 0): the batch alone does not fill the chip, so each
+    // layer is additionally split along the tokens - the slots are dense, so (layer, split) is still ONE uniform stride - and the
+    // bf16 partials are summed per layer (fp32 accumulation inside the reduction), as the per-layer path does
+    static const int64_t max_split = [] { const char* e = std::getenv("DGTD_WGRAD_SPLIT"); return e ? (int64_t)std::atol(e) : (int64_t)32; }();
+    int64_t S = n >= 16 ? 1 : std::min<int64_t>(max_split, a.M / 1024);
+    while (S > 1 && a.M % S) --S;
+    const bool dense = n == 1 || (sx == a.M * a.K && sdy == a.M * a.N && sdw == a.N * a.K);
+    bool done = false;
+    if (S >= 2 && dense) {
+      Tensor part = at::empty({n * S, a.N * a.K}, a.x.options());
+      if (dgemm_fwd::batched_dw(a.x.scalar_type(), a.dy.data_ptr(), a.x.data_ptr(), part.data_ptr(), a.N, a.K, a.M / S, (int)(n * S), (a.M / S) * a.N,
+                                (a.M / S) * a.K, a.N * a.K, a.x.options())) {
+        Tensor out = at::from_blob(a.dw, {n, a.N * a.K}, a.x.options());
+        at::sum_out(out, part.view({n, S, a.N * a.K}), {1});
+        done = true;
+      }
+    }
+    if (!done && !dgemm_fwd::batched_dw(a.x.scalar_type(), a.dy.data_ptr(), a.x.data_ptr(), a.dw, a.N, a.K, a.M, n, sdy, sx, sdw, a.x.options())) {
+      for (size_t k = i; k < j; ++k) {     // no library plan: the per-layer path, copied into the promised gradient slots
+        Tensor dw = gemm_dw(gs[k].dy, gs[k].x);
+        Tensor dst = at::from_blob(gs[k].dw, {gs[k].N, gs[k].K}, dw.options());
+        dst.copy_(dw);
+      }
+    }
+    i = j;
+  }
+}
+
 void flush_deferred() {
   std::vector<PendingReduce> todo;
   std::vector<PendingDw> dws;
+  std::vector<PendingGemm> gemms;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    gemms.swap(g_pending_gemm);
+  }
+  if (!gemms.empty()) flush_gemms(gemms);
   {
     std::lock_guard<std::mutex> lk(g_pending_mu);
     todo.swap(g_pending);
@@ -112,6 +224,7 @@ void set_deferred(bool on) {
     std::lock_guard<std::mutex> lk(g_pending_mu);
     g_pending.clear();
     g_pending_dw.clear();
+    g_pending_gemm.clear();
   } else {
     flush_deferred();
   }
@@ -119,7 +232,7 @@ void set_deferred(bool on) {
 }
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
-  return (int64_t)(g_pending.size() + g_pending_dw.size());
+  return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size());
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -129,7 +242,7 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
     on_device(x);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     Tensor w32 = f32(w), b32 = f32(b);
-    Tensor y = at::empty_like(x);
+    Tensor y = hinted(t_hint, x.scalar_type()) ? arena_slot(t_hint, ROLE_X1, x.sizes(), x.options()) : at::empty_like(x);
     Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
@@ -168,7 +281,7 @@ struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
     on_device(x);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     Tensor w32 = f32(w), b32 = f32(b);
-    Tensor y = at::empty_like(x);
+    Tensor y = hinted(t_hint, x.scalar_type()) ? arena_slot(t_hint, ROLE_X1, x.sizes(), x.options()) : at::empty_like(x);
     Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
@@ -421,7 +534,7 @@ inline Tensor gemm_dx(const Tensor& dy2, const Tensor& wc) {                    
 }
 // dW = dY^T X; long token dimensions are split into S batches (library batched GEMM) and summed in fp32: the plain GEMM has only a
 // few hundred output tiles, each reducing over all tokens (latency-bound, tools/bench_gemm.py)
-inline Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                              // [M,N]^T x [M,K] -> [N,K]
+Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                              // [M,N]^T x [M,K] -> [N,K]
   const int64_t M = dy2.size(0), N = dy2.size(1), K = x2.size(1);
   const bool bf = is16(dy2.scalar_type()) && x2.is_contiguous() && M > 0;
   hipStream_t st = (hipStream_t)stream();
@@ -438,6 +551,11 @@ inline Tensor gemm_dw(const Tensor& dy2, const Tensor& x2) {                    
   if (!(bf && dgemm::matmul_16(dy2.scalar_type(), dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), nullptr, N, K, M, true, false, 1, 0, 0, 0, dy2.options(), st)))
     at::mm_out(dw, dy2.t(), x2);
   return dw;
+}
+bool dgemm_fwd::batched_dw(at::ScalarType dt, const void* dy, const void* x, void* dw, int64_t N, int64_t K, int64_t M, int batch, int64_t s_dy, int64_t s_x,
+                           int64_t s_dw, const at::TensorOptions& o) {
+  return dgemm::matmul_16(dt, dy, x, dw, nullptr, N, K, M, true, false, batch, batch > 1 ? s_dy : 0, batch > 1 ? s_x : 0, batch > 1 ? s_dw : 0, o,
+                          (hipStream_t)stream());
 }
 inline Tensor as_rows(const Tensor& t, at::ScalarType dt) {          // [..., C] -> contiguous [rows, C] in the compute dtype
   Tensor t2 = t.reshape({-1, t.size(-1)});
@@ -495,9 +613,14 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
     Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
     Tensor pre = gemm_fwd(x2, wc, bc);
-    Tensor h = at::empty(with_last(x, w.size(0)), pre.options());
+    // under an arena hint (a block of a run of identical blocks): the GELU output = pwconv2's input goes to slot idx of the stage arena,
+    // and the backward defers dW when this node's own input already sits in its arena (written there by the hinted LayerNorm)
+    const Hint hint = t_hint;
+    const bool ar = hinted(hint, dt) && w.scalar_type() == dt;
+    Tensor h = ar ? arena_slot(hint, ROLE_X2, with_last(x, w.size(0)), pre.options()) : at::empty(with_last(x, w.size(0)), pre.options());
     Tensor h2 = h.view({-1, w.size(0)});
     at::gelu_out(h2, pre);
+    ctx->saved_data["hint"] = hint_iv(ar && in_arena(hint, ROLE_X1, x2) ? hint : Hint{});
     ctx->save_for_backward({x2, wc, pre});
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_dt"] = st_id(w);
@@ -510,7 +633,10 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     const Tensor &x2 = saved[0], &wc = saved[1], &pre = saved[2];
     Tensor dh = as_rows(g[0], pre.scalar_type());
     const int64_t rows = pre.size(0), C = pre.size(1);
-    Tensor dpre = at::empty_like(pre), db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const bool ar = hint.group >= 0 && deferring();
+    Tensor dpre = ar ? arena_slot(hint, ROLE_DY1, pre.sizes(), pre.options()) : at::empty_like(pre);
+    Tensor db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, pre.options().dtype(at::kFloat));
     if (deferring()) {
       int nb = 0;
@@ -523,9 +649,15 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     }
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
-    Tensor dw = gemm_dw(dpre, x2);
-    const auto w_dt = st_of(ctx->saved_data["w_dt"]);
-    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    Tensor dw;
+    if (ar) {
+      dw = arena_slot(hint, ROLE_DW1, wc.sizes(), wc.options());
+      park_gemm(hint, 0, x2, dpre, dw);
+    } else {
+      dw = gemm_dw(dpre, x2);
+      const auto w_dt = st_of(ctx->saved_data["w_dt"]);
+      if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    }
     return {dx, dw, db, undefined()};
   }
 };
@@ -549,6 +681,8 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     check(dgtd_scale_residual_fwd(x.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
                                   out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
     ctx->save_for_backward({h2, wc, y, s, g32});
+    const Hint hint = t_hint;
+    ctx->saved_data["hint"] = hint_iv(hinted(hint, dt) && w.scalar_type() == dt && in_arena(hint, ROLE_X2, h2) ? hint : Hint{});
     ctx->saved_data["hshape"] = h.sizes().vec();
     ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, st_id(w), st_id(b), has_g ? st_id(*gamma_) : (int64_t)at::kFloat,
                                                    h.requires_grad(), B};
@@ -563,7 +697,10 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     Tensor g = gr[0].contiguous();
     if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
     const int64_t rows = y.size(0), C = y.size(1), B = m[6];
-    Tensor dy = at::empty_like(y), db = at::empty({C}, y.options().dtype(b_dt));
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const bool ar = hint.group >= 0 && deferring();
+    Tensor dy = ar ? arena_slot(hint, ROLE_DY2, y.sizes(), y.options()) : at::empty_like(y);
+    Tensor db = at::empty({C}, y.options().dtype(b_dt));
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, y.options().dtype(at::kFloat));
     // the layer-scale gradient is deferred only when it needs no dtype conversion afterwards (gamma is an fp32 parameter on this path)
@@ -580,8 +717,14 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     }
     Tensor dh;
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
-    Tensor dw = gemm_dw(dy, h2);
-    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    Tensor dw;
+    if (ar) {
+      dw = arena_slot(hint, ROLE_DW2, wc.sizes(), wc.options());
+      park_gemm(hint, 1, h2, dy, dw);
+    } else {
+      dw = gemm_dw(dy, h2);
+      if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    }
     if (has_g && g_dt != at::kFloat) dgamma = dgamma.to(g_dt);
     return {dh, dw, db, g, undefined(), dgamma, undefined()};
   }
@@ -793,4 +936,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("set_deferred(bool on) -> ()", &set_deferred);
   m.def("flush_deferred() -> ()", &flush_deferred);
   m.def("pending_reductions() -> int", &pending_reductions);
+  m.def("arena_hint(int group, int idx, int count) -> ()", &arena_hint);
+  m.def("arena_release(int group) -> ()", &arena_release);
+  m.def("arena_bytes() -> int", &arena_bytes);
 }

@@ -316,8 +316,10 @@ class ShapePropEncoder(nn.Module):
                 t = ops.linear(_patchify(norm(t), h, w, 2), cw.flatten(1), cb)
                 h, w = h // 2, w // 2
             t4 = t.view(B, h, w, -1)
-            for blk in self.stages[i]:
-                t4 = blk.forward_nhwc(t4)
+            with ops.block_run(self, i, len(self.stages[i]), t4) as run:     # identical blocks: their weight-gradient GEMMs batch
+                for j, blk in enumerate(self.stages[i]):
+                    run.at(j)
+                    t4 = blk.forward_nhwc(t4)
             t = t4.reshape(B, h * w, -1)
             outs.append((t, h, w))
         size = (outs[0][1], outs[0][2])

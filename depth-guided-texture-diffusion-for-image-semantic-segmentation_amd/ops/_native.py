@@ -28,3 +28,58 @@ def ops():
             torch.ops.load_library(TORCH_LIB_PATH)
             _ops = torch.ops.dgtd
     return _ops
+
+
+# ------------------------------------------------------------------------------------------------ runs of identical blocks
+_NEXT_GROUP = [0]
+BATCH_WGRAD = os.environ.get("DGTD_BATCH_WGRAD", "1") != "0"
+
+
+class _Released:
+    """Frees the arenas of an owner module's groups when the module is garbage-collected."""
+
+    def __init__(self):
+        self.groups = {}       # stage -> arena group id
+
+    def __del__(self):
+        nat = _ops
+        if nat is not None:
+            for g in self.groups.values():
+                try:
+                    nat.arena_release(g)
+                except Exception:
+                    pass
+
+
+class block_run:
+    """``with block_run(owner, stage, n_blocks, x) as run: for j, blk in ...: run.at(j); x = blk(x)``
+
+    Tells the C++ nodes that the calls inside belong to block j of a run of n identical blocks (a ConvNeXt stage): under a gradient
+    reducer (deferral on, 16-bit compute) the producers of the Linear layers' inputs and output gradients then write into per-stage
+    arenas, and the n weight-gradient GEMMs of each Linear of the run become ONE strided-batched GEMM at the end of the backward pass
+    (bindings.cpp "Deferred WEIGHT GRADIENTS of the Linear layers").  A no-op otherwise (CPU, fp32, Python bindings, eval)."""
+
+    def __init__(self, owner, stage: int, n: int, x: torch.Tensor):
+        self.nat = ops() if (BATCH_WGRAD and x.is_cuda and n > 1 and torch.is_grad_enabled()) else None
+        self.n = n
+        if self.nat is not None:
+            tok = owner.__dict__.get("_dgtd_arena_token")          # lives and dies with the owner module
+            if tok is None:
+                tok = _Released()
+                object.__setattr__(owner, "_dgtd_arena_token", tok)
+            if stage not in tok.groups:
+                tok.groups[stage] = _NEXT_GROUP[0]
+                _NEXT_GROUP[0] += 1
+            self.group = tok.groups[stage]
+
+    def __enter__(self):
+        return self
+
+    def at(self, j: int) -> None:
+        if self.nat is not None:
+            self.nat.arena_hint(self.group, j, self.n)
+
+    def __exit__(self, *exc):
+        if self.nat is not None:
+            self.nat.arena_hint(-1, 0, 0)
+        return False

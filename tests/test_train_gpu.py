@@ -375,3 +375,48 @@ def test_deferred_column_reductions_are_bit_identical(dgtd):
     enc = [k for k in grads[True] if "encoder2.stages.3" in k and (k.endswith("norm.weight") or k.endswith("pwconv1.bias") or k.endswith(".gamma"))]
     assert enc and all(torch.equal(grads[True][k], grads[False][k]) for k in enc), "last ConvNeXt stage: no atomics upstream in the backward"
     assert same > len(grads[True]) // 4
+
+
+def test_batched_weight_gradient_gemms_match_per_layer_path(dgtd):
+    """Deferred weight-gradient phase of the ConvNeXt stages: under the reducer the LayerNorm / GELU outputs and the output gradients of
+    each stage live in per-stage arenas and the pwconv1 / pwconv2 weight gradients of all blocks of a stage come from ONE strided-batched
+    GEMM each at the flush.  Same gradients as the per-layer path (which sums bf16 split-K partials: the batched GEMM accumulates in
+    fp32 throughout, so it is compared at bf16 resolution), nothing left parked, arenas released with the model."""
+    import gc
+    from dgtd.ops import _native as N
+    nat = N.ops()
+    assert nat is not None
+    S, B = 64, 2
+    x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=5))
+    grads, parked = {}, {}
+    base = nat.arena_bytes()
+    try:
+        for batched in (False, True):
+            N.BATCH_WGRAD = batched
+            net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+            filler.fill_module(net)
+            net = net.cuda().train()
+            red = dgtd.dist.GradReducer(net, working_dtype=torch.bfloat16)
+            for _ in range(2):                                       # second step reuses the arenas
+                red.zero_grad()
+                loss = net(None, x, l, d, mode="loss")["loss"]
+                loss.backward()
+                parked[batched] = nat.pending_reductions()
+                red.finish()
+            assert nat.pending_reductions() == 0
+            grads[batched] = {k: p.grad.float().clone() for k, p in net.named_parameters() if p.grad is not None}
+            if batched:
+                assert nat.arena_bytes() > base
+            del net, red, loss
+            gc.collect()
+    finally:
+        N.BATCH_WGRAD = True
+    assert nat.arena_bytes() == base, "arenas must die with the model"
+    assert parked[True] >= parked[False] + 2 * (3 + 3 + 27 + 3)      # one parked GEMM per pwconv of the 36 ConvNeXt blocks
+    pw = [k for k in grads[True] if ".pwconv" in k and k.endswith("weight")]
+    assert len(pw) == 72
+    for k in pw:
+        a, b = grads[True][k], grads[False][k]
+        assert (a - b).norm() / b.norm() < 1e-2, k
+    for k in grads[True]:
+        torch.testing.assert_close(grads[True][k], grads[False][k], rtol=3e-2, atol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
