@@ -333,6 +333,130 @@ __global__ __launch_bounds__(K * 64) void dwconv_bww_batched_kernel(BwwTable tab
   if (ky == P) *reinterpret_cast<f32x2*>(wsb + (size_t)(K * K) * C) = has_bias ? accb : f32x2{0.f, 0.f};
 }
 
+// Sliding-window variant of the batched weight gradient (the default): ONE wave owns all K filter rows of an 8-column strip x 128
+// channels and walks down the image.  Each input row is loaded once per wave (the K-waves-per-workgroup kernel above loads it K times,
+// and its 7x L1/L2 re-read volume, not HBM, bounds it: 1.3 TB/s at 27 x [8,32,32,512]); the K gradient rows it meets (output rows
+// r-P..r+P) sit in a register window that shifts by one row per step.  K*K accumulators x 2 channels per lane; the 4 waves of a
+// workgroup (4 neighbouring strips) add their partials through LDS in a fixed order, so a workgroup writes one partial row set.
+template <typename T, int K, int TX, int NW>
+__global__ __launch_bounds__(NW * 64) void dwconv_bww_sw_kernel(BwwTable tab, float* __restrict__ ws, int has_bias,
+                                                                int B, int H, int W, int C, int ysplit, int xgroups) {
+  typedef typename Pair<T>::type PT;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int P = K / 2, KK = K * K;
+  extern __shared__ float red[];                                  // [NW - 1][KK + 1][128]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane2 = lane * 2;
+  int rest = blockIdx.x;
+  const int xg = rest % xgroups; rest /= xgroups;
+  const int ypart = rest % ysplit; rest /= ysplit;
+  const int b = rest % B, z = rest / B;
+  const size_t img = (size_t)b * H * W * C + (size_t)blockIdx.y * 128;
+  const T* __restrict__ x = (const T*)tab.x[z] + img;
+  const T* __restrict__ du = (const T*)tab.du[z] + img;
+  const int rows_per = (H + ysplit - 1) / ysplit;
+  const int y_begin = ypart * rows_per, y_end = min(H, y_begin + rows_per);
+  const int x0 = (xg * NW + wv) * TX;                             // this wave's strip (may lie outside the image: contributes zeros)
+  f32x2 acc[K][K], accb = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[i][j] = f32x2{0.f, 0.f};
+  if (x0 < W && y_begin < y_end) {
+    PT zero; zero[0] = (T)0.f; zero[1] = (T)0.f;
+    const bool interior = x0 - P >= 0 && x0 + TX + P <= W;
+    auto load_in = [&](int r, PT* ir) {                           // input row r (inside the image), columns x0-P .. x0+TX+P-1
+      const T* row = x + ((ptrdiff_t)r * W + (x0 - P)) * (ptrdiff_t)C;
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < TX + K - 1; ++i) ir[i] = *reinterpret_cast<const PT*>(row + i * C + lane2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TX + K - 1; ++i) {
+          const int xx = x0 + i - P;
+          ir[i] = (xx >= 0 && xx < W) ? *reinterpret_cast<const PT*>(row + i * C + lane2) : zero;
+        }
+      }
+    };
+    auto load_g = [&](int y, PT* gr) {                            // gradient row y; zeros outside this workgroup's row range
+      if (y >= y_begin && y < y_end) {
+        const T* grow = du + ((size_t)y * W + x0) * C;
+        if (x0 + TX <= W) {
+#pragma unroll
+          for (int t = 0; t < TX; ++t) gr[t] = *reinterpret_cast<const PT*>(grow + t * C + lane2);
+        } else {
+#pragma unroll
+          for (int t = 0; t < TX; ++t) gr[t] = (x0 + t < W) ? *reinterpret_cast<const PT*>(grow + t * C + lane2) : zero;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TX; ++t) gr[t] = zero;
+      }
+    };
+    // input rows this range needs: r in [max(0, y_begin-P), min(H, y_end+P)); at step r the window holds gradient rows
+    // gw[j] = row r + P - j ... i.e. filter row ky = j pairs input row r with output row y = r - ky + P
+    const int r0 = max(0, y_begin - P), r1 = min(H, y_end + P);
+    PT gw[K][TX], in_cur[TX + K - 1], in_nxt[TX + K - 1], g_nxt[TX];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load_g(r0 + P - j, gw[j]);
+    load_in(r0, in_cur);
+    for (int r = r0; r < r1; ++r) {
+      const bool more = r + 1 < r1;
+      if (more) { load_in(r + 1, in_nxt); load_g(r + 1 + P, g_nxt); }
+      f32x2 in[TX + K - 1];
+#pragma unroll
+      for (int i = 0; i < TX + K - 1; ++i) in[i] = f32x2{(float)in_cur[i][0], (float)in_cur[i][1]};
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int y = r - ky + P;
+        if (y >= y_begin && y < y_end) {                          // wave-uniform
+#pragma unroll
+          for (int t = 0; t < TX; ++t) {
+            const f32x2 g = f32x2{(float)gw[ky][t][0], (float)gw[ky][t][1]};
+            if (ky == P) accb += g;                               // y == r: every gradient row exactly once
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[ky][kx] = __builtin_elementwise_fma(g, in[t + kx], acc[ky][kx]);
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int j = K - 1; j > 0; --j)
+#pragma unroll
+          for (int t = 0; t < TX; ++t) gw[j][t] = gw[j - 1][t];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) gw[0][t] = g_nxt[t];
+#pragma unroll
+        for (int i = 0; i < TX + K - 1; ++i) in_cur[i] = in_nxt[i];
+      }
+    }
+  }
+  // waves 1..NW-1 park their partials in LDS; wave 0 adds them in wave order and writes ws[blockIdx.x][KK + 1][C]
+  if (wv > 0) {
+    float* mine = red + (size_t)(wv - 1) * (KK + 1) * 128 + lane2;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int j = 0; j < K; ++j) *reinterpret_cast<f32x2*>(mine + (i * K + j) * 128) = acc[i][j];
+    *reinterpret_cast<f32x2*>(mine + KK * 128) = accb;
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* wsb = ws + (size_t)blockIdx.x * (KK + 1) * C + blockIdx.y * 128 + lane2;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        f32x2 v = acc[i][j];
+        for (int w2 = 0; w2 < NW - 1; ++w2) v += *reinterpret_cast<const f32x2*>(red + ((size_t)w2 * (KK + 1) + i * K + j) * 128 + lane2);
+        *reinterpret_cast<f32x2*>(wsb + (size_t)(i * K + j) * C) = v;
+      }
+    f32x2 vb = accb;
+    for (int w2 = 0; w2 < NW - 1; ++w2) vb += *reinterpret_cast<const f32x2*>(red + ((size_t)w2 * (KK + 1) + KK) * 128 + lane2);
+    *reinterpret_cast<f32x2*>(wsb + (size_t)KK * C) = has_bias ? vb : f32x2{0.f, 0.f};
+  }
+}
+
 // weights [C, K*K] (Conv2d layout, dtype T) + bias [C] -> packed fp32 [ wt (K*K x C) | wt spatially flipped | bias ]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ w, const T* __restrict__ bias,
@@ -399,24 +523,45 @@ int bww_launch(const void* x, const void* du, float* grads, int has_bias, void* 
   return 0;
 }
 
-// row ranges per image so that the batched launch has >= ~6 workgroups per CU (each K waves), never fewer than 4 rows per range
-static int bww_batched_ysplit(int n, int B, int H, int C) {
-  static const int64_t target = getenv("DGTD_BWW_BATCHED_WGS") ? atol(getenv("DGTD_BWW_BATCHED_WGS")) : 1536;
-  int ys = 1;
-  while ((int64_t)n * B * (C / 128) * ys < target && H / (ys * 2) >= 4) ys *= 2;
-  return ys;
+// Launch geometry of the batched weight gradient.  Sliding-window kernel (default): a workgroup = 4 neighbouring 8-column strips x a
+// row range x 128 channels; row ranges are halved until ~1024 workgroups exist but never below 16 rows (each range re-reads K-1 halo
+// rows).  DGTD_BWW_SLIDING=0 selects the K-waves-per-workgroup kernel (whole-width row ranges).
+struct BwwGeom { int ys, xg, blocks; bool sliding; };
+static BwwGeom bww_batched_geom(int n, int B, int H, int W, int C, int K) {
+  static const bool sliding = !(getenv("DGTD_BWW_SLIDING") && atoi(getenv("DGTD_BWW_SLIDING")) == 0);
+  static const int64_t target = getenv("DGTD_BWW_BATCHED_WGS") ? atol(getenv("DGTD_BWW_BATCHED_WGS")) : (sliding ? 1024 : 1536);
+  BwwGeom g;
+  g.sliding = sliding;
+  g.xg = sliding ? (int)cdiv(cdiv(W, 8), 4) : 1;
+  g.ys = 1;
+  const int64_t wgs1 = (int64_t)n * B * (C / 128) * g.xg;
+  // measured (n = 27 x [8,32,32,512]): 1728 workgroups of 16 rows beat 864 of 32 although each re-reads K-1 halo rows
+  const int min_rows = sliding ? (int)(getenv("DGTD_BWW_MIN_ROWS") ? atol(getenv("DGTD_BWW_MIN_ROWS")) : 8) : 4;
+  while (wgs1 * g.ys < target && H / (g.ys * 2) >= min_rows) g.ys *= 2;
+  g.blocks = B * g.ys * g.xg;
+  return g;
 }
 
 template <typename T, int K, int TX>
-int bww_batched_launch(const void* const* x, const void* const* du, int n, int has_bias, float* ws, int B, int H, int W, int C, int ys,
+int bww_batched_launch(const void* const* x, const void* const* du, int n, int has_bias, float* ws, int B, int H, int W, int C, const BwwGeom& g,
                        hipStream_t s) {
+  constexpr int NW = 4;
   for (int z0 = 0; z0 < n; z0 += BW_MAX) {
     const int m = std::min(BW_MAX, n - z0);
     BwwTable tab;
     for (int i = 0; i < m; ++i) { tab.x[i] = x[z0 + i]; tab.du[i] = du[z0 + i]; }
     for (int i = m; i < BW_MAX; ++i) { tab.x[i] = nullptr; tab.du[i] = nullptr; }
-    hipLaunchKernelGGL((dwconv_bww_batched_kernel<T, K, TX>), dim3(m * B * ys, C / 128), dim3(K * 64), 0, s, tab,
-                       ws + (size_t)z0 * B * ys * (K * K + 1) * C, has_bias, B, H, W, C, ys);
+    float* wsz = ws + (size_t)z0 * g.blocks * (K * K + 1) * C;
+    if (g.sliding) {
+      const size_t lds = (size_t)(NW - 1) * (K * K + 1) * 128 * sizeof(float);
+      static bool once = [] { return hipFuncSetAttribute((const void*)dwconv_bww_sw_kernel<T, K, TX, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)((NW - 1) * (K * K + 1) * 128 * sizeof(float))) == hipSuccess; }();
+      (void)once;
+      hipLaunchKernelGGL((dwconv_bww_sw_kernel<T, K, TX, NW>), dim3(m * g.blocks, C / 128), dim3(NW * 64), lds, s, tab, wsz, has_bias, B, H, W, C, g.ys,
+                         g.xg);
+    } else {
+      hipLaunchKernelGGL((dwconv_bww_batched_kernel<T, K, TX>), dim3(m * g.blocks, C / 128), dim3(K * 64), 0, s, tab, wsz, has_bias, B, H, W, C, g.ys);
+    }
     DGTD_CHECK_LAUNCH("dwconv_bww_batched");
   }
   return 0;
@@ -425,8 +570,8 @@ int bww_batched_launch(const void* const* x, const void* const* du, int n, int h
 }  // namespace
 
 extern "C" int dgtd_dwconv_bwd_weight_batched_blocks(int n, int B, int H, int W, int C, int K) {
-  (void)W; (void)K;
-  return C % 128 == 0 && n > 0 ? B * bww_batched_ysplit(n, B, H, C) : 0;
+  (void)K;
+  return C % 128 == 0 && n > 0 ? bww_batched_geom(n, B, H, W, C, K).blocks : 0;
 }
 
 extern "C" int dgtd_dwconv_bwd_weight_batched(const void* const* x, const void* const* du, int n, int has_bias, void* workspace, int B, int H,
@@ -439,7 +584,7 @@ extern "C" int dgtd_dwconv_bwd_weight_batched(const void* const* x, const void* 
   for (int i = 0; i < n; ++i) DGTD_REQUIRE(x[i] && du[i], "dwconv_bwd_weight_batched: null tensor in layer %d", i);
   DGTD_PROF(s, DGTD_HBM, 2.0 * dgtd_esize(dt) * n * B * H * W * C, "dgtd_dwconv_bwd_weight_batched[n%d,k%d,%dx%dx%d]", n, K, H, W, C);
   hipStream_t st = (hipStream_t)s;
-  const int ys = bww_batched_ysplit(n, B, H, C);
+  const BwwGeom ys = bww_batched_geom(n, B, H, W, C, K);
   float* ws = (float*)workspace;
   if (dt == DGTD_BF16) return K == 7 ? bww_batched_launch<bf16_t, 7, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st)
                                      : bww_batched_launch<bf16_t, 3, 8>(x, du, n, has_bias, ws, B, H, W, C, ys, st);

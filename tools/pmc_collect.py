@@ -21,7 +21,7 @@ for op in sorted(os.listdir(root)):
             if r["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d*|void ", "", r["Kernel_Name"])
-            if not any(k in name for k in ("dwconv", "ln_", "sra_", "attn_delta", "colsum", "conv3x3")):
+            if not any(k in name for k in ("dwconv", "ln_", "sra_", "attn_delta", "colsum", "conv3x3", "multi_reduce", "scale_residual")):
                 continue
             e = per.setdefault(name[:60] + " grid=" + r["Grid_Size"], {"fetch": [0.0, 0], "write": [0.0, 0]})
             e[kind][0] += float(r["Counter_Value"]) * 1024 * (2 if kind == "fetch" else 1)
@@ -32,6 +32,10 @@ print(json.dumps(out, indent=1))
 
 # ---- second output (stderr -> file): HBM bytes per C-ABI call keyed like bench.py's kernel keys
 BENCH_KEYS = {
+    "dgtd_gelu_bias_bwd[rows=8192,C=2048]": ("linear_gelu_8192x512x2048", ["colsum2_kernel"]),
+    "dgtd_scale_residual_bias_bwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["colsum2_kernel"]),
+    "dgtd_scale_residual_fwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["scale_residual_fwd_kernel"]),
+    "dgtd_dwconv_bwd_weight_batched[n27,k7,32x32x512]": ("dwconv_batched_k7_n27_32x32x512", ["dwconv_bww_batched_kernel"]),
     "dgtd_dwconv_bwd_weight[k7,32x32x512]": ("dwconv_k7_32x32x512", ["dwconv_bwd_weight_kernel", "dwconv_bww_reduce"]),
     "dgtd_dwconv_fwd[k7,mode0,32x32x512]": ("dwconv_k7_32x32x512", ["dwconv_tiled_fwd_kernel"]),
     "dgtd_dwconv_bwd_weight[k7,128x128x128]": ("dwconv_k7_128x128x128", ["dwconv_bwd_weight_kernel", "dwconv_bww_reduce"]),

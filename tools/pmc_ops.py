@@ -9,7 +9,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("DGTD_TORCH_BINDINGS", "0")
+NATIVE_OPS = ("linear_gelu_8192x512x2048", "linear_residual_8192x2048x512", "dwconv_batched_k7_n27_32x32x512")   # nodes that only exist in the C++ bindings
+os.environ.setdefault("DGTD_TORCH_BINDINGS", "1" if len(sys.argv) > 1 and sys.argv[1] in NATIVE_OPS else "0")
 import dgtd  # noqa: E402
 
 dev, bf = "cuda", torch.bfloat16
@@ -61,7 +62,44 @@ def attn():
         torch.autograd.grad(y, (q, kv), g)
 
 
+def lin_gelu(rows, K, N):
+    x = torch.randn(rows, K, device=dev, dtype=bf).requires_grad_()
+    w = (torch.randn(N, K, device=dev, dtype=bf) / K ** 0.5).requires_grad_()
+    b = torch.randn(N, device=dev, dtype=bf).requires_grad_()
+    g = torch.randn(rows, N, device=dev, dtype=bf)
+    for _ in range(REPS):
+        y = dgtd.ops.linear_gelu(x, w, b)
+        torch.autograd.grad(y, (x, w, b), g)
+
+
+def lin_res(rows, K, N):
+    h = torch.randn(rows, K, device=dev, dtype=bf).requires_grad_()
+    w = (torch.randn(N, K, device=dev, dtype=bf) / K ** 0.5).requires_grad_()
+    b = torch.randn(N, device=dev, dtype=bf).requires_grad_()
+    x = torch.randn(8, rows // 8, N, device=dev, dtype=bf).requires_grad_()
+    gamma = torch.ones(N, device=dev).requires_grad_()
+    s = torch.ones(8, device=dev)
+    g = torch.randn(8, rows // 8, N, device=dev, dtype=bf)
+    for _ in range(REPS):
+        y = dgtd.ops.linear_residual(h.view(8, rows // 8, K), w, b, x, s, gamma)
+        torch.autograd.grad(y, (h, w, b, x, gamma), g)
+
+
+def dw_batched(K, n, H, C):
+    nat = dgtd.ops._native.ops()
+    layers = [(torch.randn(8, H, H, C, device=dev, dtype=bf), (torch.randn(C, 1, K, K, device=dev, dtype=bf) / K).requires_grad_(),
+               torch.randn(C, device=dev, dtype=bf).requires_grad_(), torch.randn(8, H, H, C, device=dev, dtype=bf)) for _ in range(n)]
+    for _ in range(REPS):
+        nat.set_deferred(True)
+        for x, w, b, g in layers:
+            torch.autograd.grad(dgtd.ops.dwconv_nhwc(x, w, b, False), (w, b), g)
+        nat.set_deferred(False)
+
+
 OPS = {
+    "linear_gelu_8192x512x2048": lambda: lin_gelu(8192, 512, 2048),
+    "linear_residual_8192x2048x512": lambda: lin_res(8192, 2048, 512),
+    "dwconv_batched_k7_n27_32x32x512": lambda: dw_batched(7, 27, 32, 512),
     "dwconv_k7_32x32x512": lambda: dw(7, 32, 512, False),
     "dwconv_k7_128x128x128": lambda: dw(7, 128, 128, False),
     "dwconv_k3_128x128x512": lambda: dw(3, 128, 512, True),
