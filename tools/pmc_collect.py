@@ -35,7 +35,7 @@ BENCH_KEYS = {
     "dgtd_gelu_bias_bwd[rows=8192,C=2048]": ("linear_gelu_8192x512x2048", ["colsum2_kernel"]),
     "dgtd_scale_residual_bias_bwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["colsum2_kernel"]),
     "dgtd_scale_residual_fwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["scale_residual_fwd_kernel"]),
-    "dgtd_dwconv_bwd_weight_batched[n27,k7,32x32x512]": ("dwconv_batched_k7_n27_32x32x512", ["dwconv_bww_batched_kernel"]),
+    "dgtd_dwconv_bwd_weight_batched[n27,k7,32x32x512]": ("dwconv_batched_k7_n27_32x32x512", ["dwconv_bww_sw_kernel", "dwconv_bww_batched_kernel"]),
     "dgtd_dwconv_bwd_weight[k7,32x32x512]": ("dwconv_k7_32x32x512", ["dwconv_bwd_weight_kernel", "dwconv_bww_reduce"]),
     "dgtd_dwconv_fwd[k7,mode0,32x32x512]": ("dwconv_k7_32x32x512", ["dwconv_tiled_fwd_kernel"]),
     "dgtd_dwconv_bwd_weight[k7,128x128x128]": ("dwconv_k7_128x128x128", ["dwconv_bwd_weight_kernel", "dwconv_bww_reduce"]),
