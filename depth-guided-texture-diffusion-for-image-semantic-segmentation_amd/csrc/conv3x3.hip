@@ -194,11 +194,18 @@ constexpr int lds_stride_for(int c) {   // row stride (elements) of a pixel-majo
 // (9/NS)*ceil(CI/32) (tap, 32-channel block) tiles of its filter rows, distributed round-robin over the 4 waves; loops over its
 // share of TH x TW pixel tiles, K = 16 pixels per MFMA.  NS = 3 when CI > 32 (more workgroups for the same partial-sum volume).
 // partial [Z][MTt][P][32 co][9][CB*32 ci] fp32 (+ bias partial [Z][MTt][P][32], written by the ky-group 0 workgroups).
+// The operands of convolution z come from a by-value table: the Z convolutions of one call (strided views of one tensor) or the
+// convolutions of SEPARATE calls gathered by the deferred weight-gradient phase (dgtd_conv3x3_wgrad_batched).  Several table entries
+// may feed the same weight (a module called several times per step): slot[z] is the weight, pbase[z] the first of this entry's P
+// partial rows among the Ptot rows of that weight, and the reduce kernel sums all of them - the per-call gradients are never formed.
+constexpr int WG_MAX = 32;
+struct WgTab { const void* x[WG_MAX]; const void* dy[WG_MAX]; const void* mask[WG_MAX]; int slot[WG_MAX]; int pbase[WG_MAX]; };
+struct WgOut { void* dw[WG_MAX]; void* db[WG_MAX]; };
+
 template <typename T, int CI, int TH, int TW>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            const T* __restrict__ mask, float* __restrict__ partial,
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgTab tab, float* __restrict__ partial,
                                                             float* __restrict__ partial_b, int B, int H, int W, int Co,
-                                                            int tiles_w, int tiles_h, long x_zs, long dy_zs) {
+                                                            int tiles_w, int tiles_h, int Ptot) {
   constexpr int G = CI / 8, CB = (CI + 31) / 32, XS = lds_stride_for(CI), LW = TW + 2, LP = (TH + 2) * LW, NPIX = TH * TW;
   constexpr int NS = CI > 32 ? 3 : 1, NTN = 9 * CB / NS, TPW = (NTN + 3) / 4, KS = NPIX / 16, KPR = TW / 16;
   typedef typename Vec16<T>::type bf16x8;
@@ -210,6 +217,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int p = blockIdx.x, P = gridDim.x, mt = blockIdx.y / NS, kg = blockIdx.y % NS, MTt = gridDim.y / NS, z = blockIdx.z;
   const int ntiles = B * tiles_h * tiles_w;
+  const bf16_t* __restrict__ x = (const bf16_t*)tab.x[z];
+  const bf16_t* __restrict__ dy = (const bf16_t*)tab.dy[z];
+  const bf16_t* __restrict__ mask = (const bf16_t*)tab.mask[z];
+  const int slot = tab.slot[z], prow = tab.pbase[z] + p;
   f32x16 acc[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i)
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
     const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, b = t / (tiles_w * tiles_h);
     const int h0 = th * TH, w0 = tw * TW;
     const size_t img = (size_t)b * H * W;
-    const bf16_t* xb = x + (size_t)z * x_zs + img * CI;
-    const bf16_t* db = dy + (size_t)z * dy_zs + img * Co;
-    const bf16_t* mb = mask ? mask + (size_t)z * dy_zs + img * Co : nullptr;
+    const bf16_t* xb = x + img * CI;
+    const bf16_t* db = dy + img * Co;
+    const bf16_t* mb = mask ? mask + img * Co : nullptr;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int c = tid + i * 256;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
       }
     }
   }
-  float* pp = partial + ((((size_t)z * MTt + mt) * P + p) * 32) * 9 * (CB * 32);
+  float* pp = partial + ((((size_t)slot * MTt + mt) * Ptot + prow) * 32) * 9 * (CB * 32);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int tl = wave + 4 * i;
@@ -303,15 +314,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += bred[k][tid];
-    partial_b[(((size_t)z * MTt + mt) * P + p) * 32 + tid] = s;
+    partial_b[(((size_t)slot * MTt + mt) * Ptot + prow) * 32 + tid] = s;
   }
 }
 
 // dw [Z][Co][9][CI] bf16 and db [Z][Co] bf16 from the partials (fixed summation order)
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
-                                                                   T* __restrict__ dw, T* __restrict__ db, int Z, int Co,
-                                                                   int CI, int CB, int MTt, int P) {
+                                                                   WgOut out, int Z, int Co, int CI, int CB, int MTt, int P) {
   const long n = (long)Z * Co * 9 * CI;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
@@ -333,15 +343,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
       s1 += (v4 + v5) + (v6 + v7);
     }
     for (; q < P; ++q) s0 += pp[q * ps];
-    dw[i] = (T)(s0 + s1);
+    ((T*)out.dw[z])[i - z * ((long)Co * 9 * CI)] = (T)(s0 + s1);
   }
-  if (db && i < (long)Z * Co) {
+  if (i < (long)Z * Co && out.db[i / Co]) {
     const int co = (int)(i % Co);
     const long z = i / Co;
     const float* pb = partial_b + (((size_t)z * MTt + (co >> 5)) * P) * 32 + (co & 31);
     float s = 0.f;
     for (int q = 0; q < P; ++q) s += pb[(size_t)q * 32];
-    db[i] = (T)s;
+    ((T*)out.db[z])[co] = (T)s;
   }
 }
 
@@ -399,24 +409,58 @@ bool supported(int Ci, int Co) {
   return ok(Ci) && ok(Co);
 }
 
+// n table entries feeding nslots weights (entry i -> slot[i]; every slot is fed by the same number of entries, n / nslots)
 template <typename T, int CI, int TH, int TW>
-int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* ws, int Z, int B, int H, int W, int Co,
-                 int shared_x, int P, hipStream_t st) {
+int launch_wgrad_tab(const void* const* x, const void* const* dy, const void* const* mask, const int* slot, int n, void* const* dw,
+                     void* const* db, int nslots, void* ws, int B, int H, int W, int Co, int P, hipStream_t st) {
   constexpr int CB = (CI + 31) / 32, XS = lds_stride_for(CI), LP = (TH + 2) * (TW + 2);
   constexpr size_t lds = ((size_t)LP * XS + (size_t)TH * TW * 32) * 2;
   static_assert(lds <= 65536, "wgrad tiles exceed 64 KB of LDS");
-  const int tiles_w = (int)cdiv(W, TW), tiles_h = (int)cdiv(H, TH), MTt = (int)cdiv(Co, 32);
-  const long plane = (long)B * H * W;
+  DGTD_REQUIRE(n > 0 && n <= WG_MAX && nslots > 0 && n % nslots == 0, "conv3x3_wgrad: %d convolutions / %d weights per launch (at most %d, equal shares)",
+               n, nslots, WG_MAX);
+  const int tiles_w = (int)cdiv(W, TW), tiles_h = (int)cdiv(H, TH), MTt = (int)cdiv(Co, 32), per = n / nslots, Ptot = per * P;
+  WgTab tab;
+  WgOut out;
+  int seen[WG_MAX];
+  for (int i = 0; i < WG_MAX; ++i) { seen[i] = 0; out.dw[i] = nullptr; out.db[i] = nullptr; }
+  for (int i = 0; i < WG_MAX; ++i) {
+    const int j = i < n ? i : 0;
+    tab.x[i] = x[j]; tab.dy[i] = dy[j]; tab.mask[i] = mask ? mask[j] : nullptr;
+    if (i < n) {
+      DGTD_REQUIRE(slot[i] >= 0 && slot[i] < nslots && seen[slot[i]] < per, "conv3x3_wgrad: bad weight slot %d of entry %d", slot[i], i);
+      tab.slot[i] = slot[i]; tab.pbase[i] = seen[slot[i]]++ * P;
+    } else { tab.slot[i] = 0; tab.pbase[i] = 0; }
+  }
+  for (int z = 0; z < nslots; ++z) { out.dw[z] = dw[z]; out.db[z] = db ? db[z] : nullptr; }
   float* partial = (float*)ws;
-  float* partial_b = partial + (size_t)Z * MTt * P * 32 * 9 * (CB * 32);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), Z), dim3(256), lds, st, (const T*)x, (const T*)dy,
-                     (const T*)mask, partial, partial_b, B, H, W, Co, tiles_w, tiles_h, shared_x ? 0L : plane * CI, plane * Co);
+  float* partial_b = partial + (size_t)nslots * MTt * Ptot * 32 * 9 * (CB * 32);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, CI, TH, TW>), dim3(P, MTt * (CI > 32 ? 3 : 1), n), dim3(256), lds, st, tab, partial, partial_b, B, H, W,
+                     Co, tiles_w, tiles_h, Ptot);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad");
-  const long n = (long)Z * Co * 9 * CI;
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel<T>, dim3((int)cdiv(n, 256)), dim3(256), 0, st, (const float*)partial,
-                     (const float*)partial_b, (T*)dw, (T*)db, Z, Co, CI, CB, MTt, P);
+  const long cnt = (long)nslots * Co * 9 * CI;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel<T>, dim3((int)cdiv(cnt, 256)), dim3(256), 0, st, (const float*)partial, (const float*)partial_b, out,
+                     nslots, Co, CI, CB, MTt, Ptot);
   DGTD_CHECK_LAUNCH("conv3x3_wgrad_reduce");
   return 0;
+}
+
+template <typename T, int CI, int TH, int TW>
+int launch_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* ws, int Z, int B, int H, int W, int Co,
+                 int shared_x, int P, hipStream_t st) {
+  DGTD_REQUIRE(Z <= WG_MAX, "conv3x3_wgrad: Z=%d convolutions per call (at most %d)", Z, WG_MAX);
+  const size_t plane = (size_t)B * H * W;
+  const void *xs[WG_MAX], *dys[WG_MAX], *ms[WG_MAX];
+  void *dws[WG_MAX], *dbs[WG_MAX];
+  int slots[WG_MAX];
+  for (int z = 0; z < Z; ++z) {
+    xs[z] = (const T*)x + (shared_x ? 0 : (size_t)z * plane * CI);
+    dys[z] = (const T*)dy + (size_t)z * plane * Co;
+    ms[z] = mask ? (const T*)mask + (size_t)z * plane * Co : nullptr;
+    dws[z] = (T*)dw + (size_t)z * Co * 9 * CI;
+    dbs[z] = db ? (T*)db + (size_t)z * Co : nullptr;
+    slots[z] = z;
+  }
+  return launch_wgrad_tab<T, CI, TH, TW>(xs, dys, mask ? ms : nullptr, slots, Z, dws, db ? dbs : nullptr, Z, ws, B, H, W, Co, P, st);
 }
 
 inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
@@ -463,6 +507,28 @@ extern "C" int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci,
 extern "C" int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co) {
   const int P = wgrad_splits(Z, B, H, W, Ci, Co), CB = (Ci + 31) / 32, MTt = (int)cdiv(Co, 32);
   return (int64_t)Z * MTt * P * 32 * (9 * CB * 32 + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t dgtd_conv3x3_wgrad_batched_workspace(int n, int B, int H, int W, int Ci, int Co) {
+  return dgtd_conv3x3_wgrad_workspace(n, B, H, W, Ci, Co);      // n * P partial row sets in total, however they are shared out
+}
+
+extern "C" int dgtd_conv3x3_wgrad_batched(const void* const* x, const void* const* dy, const void* const* mask, const int* slot, int n,
+                                          void* const* dw, void* const* db, int nslots, void* workspace, int B, int H, int W, int Ci, int Co,
+                                          dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(n > 0 && nslots > 0 && x && dy && slot && dw && workspace, "conv3x3_wgrad_batched: no convolutions");
+  DGTD_PROF(s, DGTD_HBM, 2.0 * n * B * H * W * ((double)Ci + (double)Co * (mask ? 2 : 1)), "dgtd_conv3x3_wgrad_batched[n%d/%d,%dx%d,%d->%d]", n, nslots, H, W, Ci, Co);
+  DGTD_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wgrad_batched: bad sizes");
+  DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_wgrad_batched: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
+  DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_wgrad_batched: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
+  hipStream_t st = (hipStream_t)s;
+  const int P = wgrad_splits(n, B, H, W, Ci, Co);
+  const bool wide = W >= 32;
+#define DGTD_WG_CASE(CI_, TH_) if (Ci == CI_) DGTD_DISPATCH_HALF(dt, return wide ? (launch_wgrad_tab<T_, CI_, TH_, 32>(x, dy, mask, slot, n, dw, db, nslots, workspace, B, H, W, Co, P, st)) \
+                                                         : (launch_wgrad_tab<T_, CI_, TH_, 16>(x, dy, mask, slot, n, dw, db, nslots, workspace, B, H, W, Co, P, st)));
+  DGTD_WG_CASE(24, 8) DGTD_WG_CASE(32, 8) DGTD_WG_CASE(64, 4) DGTD_WG_CASE(96, 4)
+#undef DGTD_WG_CASE
+  DGTD_FAIL(2, "conv3x3_wgrad_batched: no kernel for Ci=%d", Ci);
 }
 
 extern "C" int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,

@@ -173,7 +173,106 @@ static void flush_gemms(std::vector<PendingGemm>& gs) {
   }
 }
 
+// Deferred WEIGHT GRADIENTS of the single dense 3x3 convolutions (Hitnet CAB bodies, conv4: small maps, 20-40 us launches that
+// write several times their input in partial sums).  Parked per call; at the flush all calls of one geometry go through ONE
+// dgtd_conv3x3_wgrad_batched launch.  A module called m times per step (the CABs of the iterative decoder) has ONE gradient tensor:
+// the first parked call hands it to autograd, the later calls return nothing, and the reduce kernel sums the partials of all m calls
+// into it (no per-call gradients, no autograd adds).  That is only sound when EVERY call of the weight in this step is deferred into
+// the same launch: the forward registers (weight, geometry) pairs, and a weight seen with two geometries, or through a non-leaf
+// tensor, keeps the immediate path for the whole step.
+struct ConvKey { int B, H, W, Ci, Co; int dt; bool operator==(const ConvKey& o) const { return B == o.B && H == o.H && W == o.W && Ci == o.Ci && Co == o.Co && dt == o.dt; } };
+struct ConvSeen { ConvKey k; bool mixed; };
+struct ConvDest { void* dw; void* db; };
+struct PendingConv { Tensor x, dy, mask; const void* w; ConvKey k; };
+static std::map<const void*, ConvSeen> g_conv_seen;      // forward registry of this step
+static std::map<const void*, ConvDest> g_conv_dest;      // backward: weight -> the one gradient tensor handed to autograd
+static std::vector<PendingConv> g_pending_conv;
+
+inline bool conv_defer_on() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_DEFER_CONV3X3"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+// forward: note that this weight runs with this geometry; returns whether the call may be deferred as far as the forward can tell
+inline bool conv_register(const Tensor& w_arg, const Tensor& w, const ConvKey& k) {
+  if (!deferring() || !conv_defer_on()) return false;
+  const bool leaf = w_arg.requires_grad() && !w_arg.grad_fn() && w_arg.data_ptr() == w.data_ptr();
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  auto it = g_conv_seen.find(w.data_ptr());
+  if (it == g_conv_seen.end()) g_conv_seen.emplace(w.data_ptr(), ConvSeen{k, !leaf});
+  else if (!(it->second.k == k) || !leaf) it->second.mixed = true;
+  return leaf;
+}
+// backward: park this call; dw / db are set only for the first parked call of the weight.  false: take the immediate path.
+inline bool conv_park(const Tensor& x, const Tensor& dy, const Tensor& mask, const Tensor& w, const ConvKey& k, bool has_b, Tensor& dw, Tensor& db) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  auto seen = g_conv_seen.find(w.data_ptr());
+  if (seen == g_conv_seen.end() || seen->second.mixed) return false;
+  auto it = g_conv_dest.find(w.data_ptr());
+  if (it == g_conv_dest.end()) {
+    dw = at::empty_like(w);
+    if (has_b) db = at::empty({k.Co}, w.options());
+    g_conv_dest.emplace(w.data_ptr(), ConvDest{dw.data_ptr(), has_b ? db.data_ptr() : nullptr});
+  }
+  g_pending_conv.push_back(PendingConv{x, dy, mask, w.data_ptr(), k});
+  return true;
+}
+static void flush_convs(std::vector<PendingConv>& cs, const std::map<const void*, ConvDest>& dest) {
+  std::vector<bool> done(cs.size(), false);
+  for (size_t i = 0; i < cs.size(); ++i) {
+    if (done[i]) continue;
+    // all calls of this geometry, grouped by weight
+    std::vector<const void*> weights;
+    std::map<const void*, std::vector<size_t>> by_w;
+    for (size_t j = i; j < cs.size(); ++j)
+      if (!done[j] && cs[j].k == cs[i].k && cs[j].x.device() == cs[i].x.device()) {
+        done[j] = true;
+        if (!by_w.count(cs[j].w)) weights.push_back(cs[j].w);
+        by_w[cs[j].w].push_back(j);
+      }
+    // one launch per call count (a launch needs equal shares), at most 32 convolutions each
+    std::map<size_t, std::vector<const void*>> by_count;
+    for (auto w : weights) by_count[by_w[w].size()].push_back(w);
+    const ConvKey& k = cs[i].k;
+    for (auto& bc : by_count) {
+      const size_t per = bc.first;
+      TORCH_CHECK(per <= 32, "dgtd conv3x3: one weight used ", per, " times per step (deferred weight gradient takes at most 32)");
+      const size_t wmax = 32 / per;
+      for (size_t w0 = 0; w0 < bc.second.size(); w0 += wmax) {
+        const size_t nw = std::min(wmax, bc.second.size() - w0);
+        std::vector<const void*> xs, dys, ms;
+        std::vector<int> slot;
+        std::vector<void*> dws, dbs;
+        bool any_b = false;
+        for (size_t a = 0; a < nw; ++a) {
+          const void* w = bc.second[w0 + a];
+          const ConvDest& d = dest.at(w);
+          dws.push_back(d.dw); dbs.push_back(d.db); any_b = any_b || d.db;
+          for (size_t j : by_w[w]) {
+            xs.push_back(cs[j].x.data_ptr()); dys.push_back(cs[j].dy.data_ptr());
+            ms.push_back(cs[j].mask.defined() ? cs[j].mask.data_ptr() : nullptr);
+            slot.push_back((int)a);
+          }
+        }
+        const int n = (int)xs.size();
+        Tensor ws = at::empty({dgtd_conv3x3_wgrad_batched_workspace(n, k.B, k.H, k.W, k.Ci, k.Co)}, cs[i].x.options().dtype(at::kByte));
+        check(dgtd_conv3x3_wgrad_batched(xs.data(), dys.data(), ms.data(), slot.data(), n, dws.data(), any_b ? dbs.data() : nullptr, (int)nw, ws.data_ptr(),
+                                         k.B, k.H, k.W, k.Ci, k.Co, (dgtd_dtype)k.dt, stream()), "dgtd_conv3x3_wgrad_batched");
+      }
+    }
+  }
+}
+
 void flush_deferred() {
+  {
+    std::vector<PendingConv> convs;
+    std::map<const void*, ConvDest> dest;
+    {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      convs.swap(g_pending_conv);
+      dest.swap(g_conv_dest);
+    }
+    if (!convs.empty()) flush_convs(convs, dest);
+  }
   std::vector<PendingReduce> todo;
   std::vector<PendingDw> dws;
   std::vector<PendingGemm> gemms;
@@ -225,6 +324,9 @@ void set_deferred(bool on) {
     g_pending.clear();
     g_pending_dw.clear();
     g_pending_gemm.clear();
+    g_pending_conv.clear();
+    g_conv_dest.clear();
+    g_conv_seen.clear();
   } else {
     flush_deferred();
   }
@@ -232,7 +334,7 @@ void set_deferred(bool on) {
 }
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
-  return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size());
+  return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size() + g_pending_conv.size());
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -735,7 +837,7 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
 // raw form: x [Z|1,B,H,W,Ci], w [Z,Co,3,3,Ci], b [Z,Co]? -> y [Z,B,H,W,Co]
 struct ConvGeom { int Z, B, H, W, Ci, Co; bool shared; };
 inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor& y_mask, const Tensor& dy, const ConvGeom& g, bool need_dx,
-                                 bool has_b, Tensor& dx, Tensor& dw, Tensor& db) {
+                                 bool has_b, Tensor& dx, Tensor& dw, Tensor& db, bool skip_wgrad = false) {
   const void* mask = y_mask.defined() ? y_mask.data_ptr() : nullptr;
   if (need_dx) {
     Tensor wt = at::empty({g.Z, g.Ci, 3, 3, g.Co}, w.options());
@@ -743,6 +845,7 @@ inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor&
     check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, code(dy), stream()),
           "dgtd_conv3x3_fwd (input gradient)");
   }
+  if (skip_wgrad) return;                          // weight gradient parked for the deferred phase
   Tensor ws = at::empty({dgtd_conv3x3_wgrad_workspace(g.Z, g.B, g.H, g.W, g.Ci, g.Co)}, x.options().dtype(at::kByte));
   check(dgtd_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), mask, dw.data_ptr(), has_b ? db.data_ptr() : nullptr, ws.data_ptr(), g.Z, g.B, g.H,
                            g.W, g.Ci, g.Co, g.shared ? 1 : 0, code(x), stream()), "dgtd_conv3x3_wgrad");
@@ -794,6 +897,8 @@ struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
     ctx->save_for_backward({x, w, relu ? y : Tensor()});
     ctx->saved_data["has_b"] = has_b;
     ctx->saved_data["need_dx"] = x_.requires_grad();
+    ctx->saved_data["defer"] = conv_register(w_, w, ConvKey{g.B, g.H, g.W, g.Ci, g.Co, (int)code(x)}) &&
+                               (!has_b || (b_->requires_grad() && !b_->grad_fn() && b_->data_ptr() == b.data_ptr()));
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -803,8 +908,11 @@ struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
     ConvGeom g{1, (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)w.size(1), (int)w.size(0), false};
     Tensor dy = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dx = need_dx ? at::empty_like(x) : Tensor();
-    Tensor dw = at::empty_like(w), db = has_b ? at::empty({g.Co}, w.options()) : Tensor();
-    conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db);
+    Tensor dw, db;
+    const bool parked = ctx->saved_data["defer"].toBool() && deferring() &&
+                        conv_park(x, dy, ym, w, ConvKey{g.B, g.H, g.W, g.Ci, g.Co, (int)code(x)}, has_b, dw, db);
+    if (!parked) { dw = at::empty_like(w); db = has_b ? at::empty({g.Co}, w.options()) : Tensor(); }
+    conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db, parked);
     return {dx, dw, db, undefined()};
   }
 };

@@ -246,6 +246,14 @@ int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_strea
 /* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) of dtype dt, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).
  * workspace: dgtd_conv3x3_wgrad_workspace(...) bytes of per-workgroup partial sums, reduced in a fixed order.                   */
 int64_t dgtd_conv3x3_wgrad_workspace(int Z, int B, int H, int W, int Ci, int Co);
+/* Deferred weight-gradient phase: n convolutions of SEPARATE calls (same geometry) in one launch, feeding nslots weights.  x, dy, mask
+ * (mask: NULL, or n pointers each of which may be NULL), slot: HOST arrays of n; slot[i] in [0, nslots) names the weight
+ * entry i contributes to, and every weight receives exactly n / nslots entries (a module called that many times per step): dw[slot] =
+ * sum over its entries, formed directly from the partial sums - the per-call gradients never exist.  dw, db (NULL or nslots pointers):
+ * HOST arrays.  n <= 32.                                                                                                          */
+int64_t dgtd_conv3x3_wgrad_batched_workspace(int n, int B, int H, int W, int Ci, int Co);
+int dgtd_conv3x3_wgrad_batched(const void* const* x, const void* const* dy, const void* const* mask, const int* slot, int n, void* const* dw,
+                               void* const* db, int nslots, void* workspace, int B, int H, int W, int Ci, int Co, dgtd_dtype dt, dgtd_stream s);
 int dgtd_conv3x3_wgrad(const void* x, const void* dy, const void* mask, void* dw, void* db, void* workspace, int Z, int B,
                        int H, int W, int Ci, int Co, int shared_x, dgtd_dtype dt, dgtd_stream s);
 

@@ -535,6 +535,45 @@ def test_dwconv_weight_gradients_deferred_and_batched(dgtd, K, L, B, H, W, C, dt
             assert (gr[1].float() - rw[1]).norm() / rw[1].norm() < tol, "bias gradient"
 
 
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_conv3x3_weight_gradients_deferred_batched_and_shared(dgtd, half):
+    """Deferred weight-gradient phase of the single 3x3 convolutions: weights used 4x / 4x / 1x per step at one geometry, one weight at a
+    second geometry and one weight at TWO geometries (must keep the immediate path).  Every weight's accumulated gradient (autograd
+    semantics: sum over its calls) against fp32 F.conv2d; the shared weights receive exactly one gradient tensor."""
+    nat = dgtd.ops._native.ops()
+    if nat is None:
+        pytest.skip("deferral lives in the C++ binding layer")
+    def leaf(co, ci, seed, bias=False):
+        w = (_rand(co, ci, 3, 3, seed=seed) * 0.05).to(half).contiguous(memory_format=torch.channels_last).requires_grad_()
+        b = (0.1 * _rand(co, seed=seed + 1)).to(half).requires_grad_() if bias else None
+        return w, b
+    wa, wb_, wc, wd, we = leaf(96, 96, 1), leaf(96, 96, 3), leaf(96, 96, 5, True), leaf(64, 64, 7), leaf(32, 32, 9)
+    calls = [(wa, 16)] * 4 + [(wb_, 16)] * 4 + [(wc, 16)] + [(wd, 32)] * 2 + [(we, 16), (we, 32)]
+    xs = [(_rand(2, w.shape[1], S, S, seed=20 + i).to(half).contiguous(memory_format=torch.channels_last).requires_grad_(),
+           _rand(2, w.shape[0], S, S, seed=60 + i).to(half).contiguous(memory_format=torch.channels_last)) for i, ((w, _), S) in enumerate(calls)]
+    nat.set_deferred(True)
+    try:
+        ys = [dgtd.ops.conv3x3(x, w, b) for ((w, b), S), (x, g) in zip(calls, xs)]
+        torch.autograd.backward(ys, [g for _, g in xs])
+        assert nat.pending_reductions() == 4 + 4 + 1 + 2              # `we` runs at two geometries: not parked
+    finally:
+        nat.set_deferred(False)
+    assert nat.pending_reductions() == 0
+    for w, b in (wa, wb_, wc, wd, we):
+        wr = w.detach().float().requires_grad_()
+        br = b.detach().float().requires_grad_() if b is not None else None
+        refs = [F.conv2d(x.detach().float(), wr, br, padding=1) for ((w2, _), S), (x, g) in zip(calls, xs) if w2 is w]
+        gs = [g.float() for ((w2, _), S), (x, g) in zip(calls, xs) if w2 is w]
+        torch.autograd.backward(refs, gs)
+        assert (w.grad.float() - wr.grad).norm() / wr.grad.norm() < 2e-2, f"weight {tuple(w.shape)} used {len(refs)}x"
+        if b is not None:
+            assert (b.grad.float() - br.grad).norm() / br.grad.norm() < 2e-2
+    for (x, g), ((w, b), S) in zip(xs, calls):                       # input gradients are immediate either way
+        xr = x.detach().float().requires_grad_()
+        F.conv2d(xr, w.detach().float(), None if b is None else b.detach().float(), padding=1).backward(g.float())
+        torch.testing.assert_close(x.grad.float(), xr.grad, atol=5e-2, rtol=5e-2)
+
+
 @pytest.mark.parametrize("scale", [2, 4, 8])
 @pytest.mark.parametrize("half", [torch.float32] + HALVES, ids=str)
 def test_prompt_tail_weight_gradient_with_channels_last_weights(dgtd, scale, half):
