@@ -187,10 +187,17 @@ struct PendingConv { Tensor x, dy, mask; const void* w; ConvKey k; };
 static std::map<const void*, ConvSeen> g_conv_seen;      // forward registry of this step
 static std::map<const void*, ConvDest> g_conv_dest;      // backward: weight -> the one gradient tensor handed to autograd
 static std::vector<PendingConv> g_pending_conv;
+// the one PReLU slope shared by every activation of the decoder (cod.py:686): all backward calls of a step add into ONE fp32 accumulator
+// (first call: zeroed here and handed to autograd through a parked 1x1 "reduction" that converts it; later calls return nothing)
+static std::map<const void*, Tensor> g_prelu_acc;
 
+// Deferrals that hand ONE gradient tensor to autograd for several calls are only sound when nothing is flushed between the first and
+// the last of those calls: the reducer switches them off when it gathers buckets from inside the backward pass (eager overlap mode).
+static std::atomic<bool> g_shared_ok{true};
+void set_shared_deferral(bool on) { g_shared_ok.store(on); }
 inline bool conv_defer_on() {
   static const bool on = [] { const char* e = std::getenv("DGTD_DEFER_CONV3X3"); return !e || std::atoi(e) != 0; }();
-  return on;
+  return on && g_shared_ok.load(std::memory_order_relaxed);
 }
 // forward: note that this weight runs with this geometry; returns whether the call may be deferred as far as the forward can tell
 inline bool conv_register(const Tensor& w_arg, const Tensor& w, const ConvKey& k) {
@@ -270,6 +277,7 @@ void flush_deferred() {
       std::lock_guard<std::mutex> lk(g_pending_mu);
       convs.swap(g_pending_conv);
       dest.swap(g_conv_dest);
+      g_prelu_acc.clear();
     }
     if (!convs.empty()) flush_convs(convs, dest);
   }
@@ -327,6 +335,7 @@ void set_deferred(bool on) {
     g_pending_conv.clear();
     g_conv_dest.clear();
     g_conv_seen.clear();
+    g_prelu_acc.clear();
   } else {
     flush_deferred();
   }
@@ -929,6 +938,7 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     check(dgtd_prelu_fwd(x.data_ptr(), a32.data_ptr<float>(), y.data_ptr(), x.numel(), code(x), stream()), "dgtd_prelu_fwd");
     ctx->save_for_backward({x, a32});
     ctx->saved_data["a_dt"] = st_id(a);
+    ctx->saved_data["a_key"] = (a.requires_grad() && !a.grad_fn()) ? (int64_t)(intptr_t)a.data_ptr() : (int64_t)0;
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -937,6 +947,25 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     Tensor g = gr[0];
     if (g.scalar_type() != x.scalar_type() || g.strides() != x.strides()) g = at::empty_like(x).copy_(g);
     Tensor dx = at::empty_like(x);
+    const void* key = (const void*)(intptr_t)ctx->saved_data["a_key"].toInt();
+    if (key && deferring() && g_shared_ok.load(std::memory_order_relaxed)) {
+      Tensor acc, ret;
+      {
+        std::lock_guard<std::mutex> lk(g_pending_mu);
+        auto it = g_prelu_acc.find(key);
+        if (it == g_prelu_acc.end()) {
+          acc = at::zeros({1}, x.options().dtype(at::kFloat));
+          ret = at::empty({1}, x.options().dtype(st_of(ctx->saved_data["a_dt"])));
+          g_prelu_acc.emplace(key, acc);
+          g_pending.push_back(PendingReduce{dgtd_reduce_entry{acc.data_ptr<float>(), 1, 1, nullptr, 0, ret.data_ptr(), (int32_t)code(ret), 0, 0, nullptr}, acc});
+        } else {
+          acc = it->second;
+        }
+      }
+      check(dgtd_prelu_bwd(x.data_ptr(), g.data_ptr(), a32.data_ptr<float>(), dx.data_ptr(), acc.data_ptr<float>(), x.numel(), code(x), stream()),
+            "dgtd_prelu_bwd");
+      return {dx, ret};
+    }
     Tensor da = at::zeros({1}, x.options().dtype(at::kFloat));
     check(dgtd_prelu_bwd(x.data_ptr(), g.data_ptr(), a32.data_ptr<float>(), dx.data_ptr(), da.data_ptr<float>(), x.numel(), code(x), stream()),
           "dgtd_prelu_bwd");
@@ -1044,6 +1073,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("set_deferred(bool on) -> ()", &set_deferred);
   m.def("flush_deferred() -> ()", &flush_deferred);
   m.def("pending_reductions() -> int", &pending_reductions);
+  m.def("set_shared_deferral(bool on) -> ()", &set_shared_deferral);
   m.def("arena_hint(int group, int idx, int count) -> ()", &arena_hint);
   m.def("arena_release(int group) -> ()", &arena_release);
   m.def("arena_bytes() -> int", &arena_bytes);

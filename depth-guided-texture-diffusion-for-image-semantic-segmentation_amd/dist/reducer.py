@@ -213,6 +213,8 @@ class GradReducer:
             from ..ops import _native
             nat = _native.ops()
             if nat is not None:
+                if on:      # one gradient tensor for all calls of a shared weight needs a single flush, after the whole backward pass
+                    nat.set_shared_deferral(not self.overlap)
                 nat.set_deferred(on)
 
     def _flush_deferred(self) -> None:

@@ -574,6 +574,36 @@ def test_conv3x3_weight_gradients_deferred_batched_and_shared(dgtd, half):
         torch.testing.assert_close(x.grad.float(), xr.grad, atol=5e-2, rtol=5e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+def test_prelu_shared_slope_gradient_under_deferral(dgtd, dtype):
+    """One nn.PReLU() slope shared by every activation (cod.py:686): under deferral all backward calls add into one fp32 accumulator
+    and autograd receives a single gradient, converted at the flush.  Against fp32 torch.prelu summed over the calls; with shared
+    deferral off (eager overlap mode of the reducer) the per-call path must give the same value."""
+    nat = dgtd.ops._native.ops()
+    if nat is None:
+        pytest.skip("deferral lives in the C++ binding layer")
+    res = {}
+    for shared in (True, False):
+        a = torch.full((1,), 0.25, device="cuda", dtype=dtype).requires_grad_()
+        xs = [_rand(2, 32, 16, 16, seed=30 + i, dtype=dtype).requires_grad_() for i in range(5)]
+        gs = [_rand(2, 32, 16, 16, seed=40 + i, dtype=dtype) for i in range(5)]
+        nat.set_shared_deferral(shared)
+        nat.set_deferred(True)
+        try:
+            torch.autograd.backward([dgtd.ops.prelu(x, a) for x in xs], gs)
+        finally:
+            nat.set_deferred(False)
+            nat.set_shared_deferral(True)
+        ar = a.detach().float().requires_grad_()
+        per_call = [torch.autograd.grad(torch.prelu(x.detach().float(), ar), ar, g.float())[0] for x, g in zip(xs, gs)]
+        ref, scale = sum(per_call), sum(p.abs() for p in per_call).item()     # the calls cancel: the error scale is that of the terms
+        tol = (1e-5 if dtype == torch.float32 else 8e-3) * scale              # 16-bit: the per-call path rounds every term to 16 bits
+        assert abs(a.grad.float().item() - ref.item()) <= tol, (shared, a.grad.item(), ref.item(), scale)
+        res[shared] = a.grad.float().item()
+        if shared and dtype != torch.float32:                                 # one fp32 accumulator, one rounding at the end
+            assert abs(res[True] - ref.item()) <= 2 ** -8 * abs(ref.item()) + 1e-4 * scale
+
+
 @pytest.mark.parametrize("scale", [2, 4, 8])
 @pytest.mark.parametrize("half", [torch.float32] + HALVES, ids=str)
 def test_prompt_tail_weight_gradient_with_channels_last_weights(dgtd, scale, half):
