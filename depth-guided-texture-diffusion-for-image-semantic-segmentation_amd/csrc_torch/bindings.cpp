@@ -78,12 +78,24 @@ inline void park_dw(const Tensor& x, const Tensor& du, Tensor& dw, Tensor& db, b
 // producers of X (LayerNorm output, GELU output) and of dY (GELU' / layer-scale backward) write straight into slot i of a
 // per-(group, role) arena [count, rows, cols] instead of a fresh allocation - no copies - and the weight gradient itself is slot i
 // of a dW arena handed to autograd as the gradient tensor and filled at the flush (same contract as the parked reductions).
-enum ArenaRole { ROLE_X1 = 0, ROLE_X2 = 1, ROLE_DY1 = 2, ROLE_DY2 = 3, ROLE_DW1 = 4, ROLE_DW2 = 5 };
+// Arena roles of a block: X[k] = input of its k-th deferred Linear, DY[k] = gradient w.r.t. that Linear's output, DW[k] = its weight
+// gradient.  The module says which role the NEXT arena-capable node writes (arena_roles: forward output -> X[out]; the gradients its
+// backward produces -> DY[ga], DY[gb]); a Linear node finds its own k by looking its input / output-gradient pointers up in the arenas.
+constexpr int ROLE_X = 0, ROLE_DY = 8, ROLE_DW = 16, NROLE = 8;
 struct Hint { int64_t group = -1; int idx = 0, count = 0; };
+struct Roles { int out = -1, ga = -1, gb = -1; };
 static thread_local Hint t_hint;
+static thread_local Roles t_roles;
+void arena_roles(int64_t out, int64_t ga, int64_t gb) { t_roles = Roles{(int)out, (int)ga, (int)gb}; }
+inline int take_out_role() { const int r = t_roles.out; t_roles.out = -1; return r < NROLE ? r : -1; }
+inline std::pair<int, int> take_grad_roles() {
+  const std::pair<int, int> r{t_roles.ga < NROLE ? t_roles.ga : -1, t_roles.gb < NROLE ? t_roles.gb : -1};
+  t_roles.ga = t_roles.gb = -1;
+  return r;
+}
 static std::map<std::pair<int64_t, int>, Tensor> g_arenas;
 
-void arena_hint(int64_t group, int64_t idx, int64_t count) { t_hint = Hint{count > 1 ? group : -1, (int)idx, (int)count}; }
+void arena_hint(int64_t group, int64_t idx, int64_t count) { t_hint = Hint{count > 1 ? group : -1, (int)idx, (int)count}; t_roles = Roles{}; }
 void arena_release(int64_t group) {
   std::lock_guard<std::mutex> lk(g_pending_mu);
   for (auto it = g_arenas.begin(); it != g_arenas.end();) it = it->first.first == group ? g_arenas.erase(it) : std::next(it);
@@ -115,8 +127,16 @@ inline bool in_arena(const Hint& h, int role, const Tensor& t) {       // is t e
   return it != g_arenas.end() && it->second.defined() && it->second.size(0) == h.count && t.is_contiguous() &&
          it->second.numel() / h.count == t.numel() && t.data_ptr() == (char*)it->second.data_ptr() + (int64_t)h.idx * t.numel() * t.element_size();
 }
-inline c10::IValue hint_iv(const Hint& h) { return std::vector<int64_t>{h.group, h.idx, h.count}; }
+inline int find_role(const Hint& h, int base, const Tensor& t) {      // k with t == slot idx of arena base + k, or -1
+  if (h.group < 0) return -1;
+  for (int k = 0; k < NROLE; ++k)
+    if (in_arena(h, base + k, t)) return k;
+  return -1;
+}
+// what a node keeps for its backward: the hint + up to two role indices
+inline c10::IValue hint_iv(const Hint& h, int r0 = -1, int r1 = -1) { return std::vector<int64_t>{h.group, h.idx, h.count, r0, r1}; }
 inline Hint hint_of(const c10::IValue& v) { auto m = v.toIntVector(); return Hint{m[0], (int)m[1], (int)m[2]}; }
+inline int role_of(const c10::IValue& v, int i) { return (int)v.toIntVector()[3 + i]; }
 
 struct PendingGemm { int64_t group; int which, idx; Tensor x, dy; void* dw; int64_t M, N, K; };   // dW [N,K] = dy[M,N]^T x[M,K]
 static std::vector<PendingGemm> g_pending_gemm;
@@ -353,7 +373,8 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
     on_device(x);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     Tensor w32 = f32(w), b32 = f32(b);
-    Tensor y = hinted(t_hint, x.scalar_type()) ? arena_slot(t_hint, ROLE_X1, x.sizes(), x.options()) : at::empty_like(x);
+    const int out_role = take_out_role();
+    Tensor y = (out_role >= 0 && hinted(t_hint, x.scalar_type())) ? arena_slot(t_hint, ROLE_X + out_role, x.sizes(), x.options()) : at::empty_like(x);
     Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
@@ -392,7 +413,8 @@ struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
     on_device(x);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     Tensor w32 = f32(w), b32 = f32(b);
-    Tensor y = hinted(t_hint, x.scalar_type()) ? arena_slot(t_hint, ROLE_X1, x.sizes(), x.options()) : at::empty_like(x);
+    const int out_role = take_out_role();
+    Tensor y = (out_role >= 0 && hinted(t_hint, x.scalar_type())) ? arena_slot(t_hint, ROLE_X + out_role, x.sizes(), x.options()) : at::empty_like(x);
     Tensor stats = at::empty({2, rows}, x.options().dtype(at::kFloat));
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
@@ -433,7 +455,12 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
     on_device(q); on_device(kv);
     const int64_t B = q.size(0), N = q.size(1), C = q.size(2), Nkv = kv.size(1);
     TORCH_CHECK(C == heads * 64 && kv.size(2) == 2 * C && kv.scalar_type() == q.scalar_type(), "sra_attention: bad shapes");
-    Tensor out = at::empty_like(q);
+    const Hint hint = t_hint;
+    const int out_role = take_out_role();
+    const auto groles = take_grad_roles();
+    const bool ar = hinted(hint, q.scalar_type());
+    Tensor out = (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, q.sizes(), q.options()) : at::empty_like(q);
+    ctx->saved_data["hint"] = hint_iv(ar ? hint : Hint{}, groles.first, groles.second);
     Tensor lse = at::empty({B, heads, N}, q.options().dtype(at::kFloat));
     check(dgtd_sra_attn_fwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)N, (int)Nkv, (int)heads,
                             (float)scale, code(q), stream()), "dgtd_sra_attn_fwd");
@@ -450,12 +477,20 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
     const int64_t B = q.size(0), N = q.size(1), Nkv = kv.size(1);
     Tensor dout = g[0].contiguous();
     if (dout.scalar_type() != q.scalar_type()) dout = dout.to(q.scalar_type());
-    Tensor dq = at::empty_like(q);
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int ra = role_of(ctx->saved_data["hint"], 0), rb = role_of(ctx->saved_data["hint"], 1);
+    const bool ar = hint.group >= 0 && deferring();
+    Tensor dq = (ar && ra >= 0) ? arena_slot(hint, ROLE_DY + ra, q.sizes(), q.options()) : at::empty_like(q);
     Tensor dkv = at::zeros(kv.sizes(), kv.options().dtype(at::kFloat));
     Tensor ws = at::empty({dgtd_sra_attn_bwd_workspace((int)B, (int)N, (int)heads)}, q.options().dtype(at::kByte));
     check(dgtd_sra_attn_bwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dq.data_ptr(),
                             dkv.data_ptr<float>(), ws.data_ptr(), (int)B, (int)N, (int)Nkv, (int)heads, (float)scale, code(q), stream()),
           "dgtd_sra_attn_bwd");
+    if (ar && rb >= 0 && kv.scalar_type() != at::kFloat) {
+      Tensor dkv16 = arena_slot(hint, ROLE_DY + rb, kv.sizes(), kv.options());
+      dkv16.copy_(dkv);
+      return {dq, dkv16, undefined(), undefined()};
+    }
     return {dq, dkv.to(kv.scalar_type()), undefined(), undefined()};
   }
 };
@@ -482,8 +517,8 @@ inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias
 }
 
 struct DwConvFn : public torch::autograd::Function<DwConvFn> {
-  static Tensor launch(const Tensor& x, const float* wt, const float* bias, const Tensor* aux, int mode, int K) {
-    Tensor y = at::empty_like(x);
+  static Tensor launch(const Tensor& x, const float* wt, const float* bias, const Tensor* aux, int mode, int K, Tensor y = Tensor()) {
+    if (!y.defined()) y = at::empty_like(x);
     check(dgtd_dwconv_fwd(x.data_ptr(), wt, bias, aux ? aux->data_ptr() : nullptr, y.data_ptr(), (int)x.size(0), (int)x.size(1),
                           (int)x.size(2), (int)x.size(3), K, mode, code(x), stream()), "dgtd_dwconv_fwd");
     return y;
@@ -500,7 +535,13 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight),
                            stream()), "dgtd_dwconv_pack");
     const float* base = packed.data_ptr<float>();
-    Tensor y = launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, gelu ? 1 : 0, (int)K);
+    const Hint hint = t_hint;
+    const int out_role = take_out_role();
+    const auto groles = take_grad_roles();
+    const bool ar = hinted(hint, x.scalar_type());
+    Tensor y = launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, gelu ? 1 : 0, (int)K,
+                      (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, x.sizes(), x.options()) : Tensor());
+    ctx->saved_data["hint"] = hint_iv(ar ? hint : Hint{}, groles.first);
     ctx->save_for_backward({x, packed});
     ctx->saved_data["gelu"] = gelu;
     ctx->saved_data["K"] = K;
@@ -519,7 +560,10 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     const float* base = packed.data_ptr<float>();
     const float* bias = has_bias ? base + 2 * KK * C : nullptr;
     Tensor du = gelu ? launch(x, base, bias, &dy, 2, (int)K) : dy;          // through the GELU: recompute the pre-activation
-    Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);     // bwd-data = same kernel, flipped filter
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int ra = role_of(ctx->saved_data["hint"], 0);
+    Tensor dx = launch(du, base + KK * C, nullptr, nullptr, 0, (int)K,      // bwd-data = same kernel, flipped filter
+                       (hint.group >= 0 && ra >= 0 && deferring()) ? arena_slot(hint, ROLE_DY + ra, x.sizes(), x.options()) : Tensor());
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
     dwconv_weight_grads(x, du, has_bias, C, K, dw, db);
@@ -693,6 +737,11 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     Tensor out = at::empty(with_last(x, w.size(0)), x2.options());
     gemm_fwd(x2, wc, bc, out.view({-1, w.size(0)}));
     ctx->save_for_backward({x2, wc});
+    // a Linear of a run of identical blocks whose input was written into an arena (PVT q / kv / fc1): its weight gradient is deferred
+    // when the output gradient arrives in an arena slot as well (attention / depthwise backward outputs)
+    const Hint hint = t_hint;
+    const int xr = (hinted(hint, dt) && w.scalar_type() == dt) ? find_role(hint, ROLE_X, x2) : -1;
+    ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_dt"] = st_id(w);
     ctx->saved_data["b_dt"] = has_b ? st_id(*b_) : (int64_t)-1;
@@ -705,9 +754,17 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     Tensor dy2 = as_rows(g[0], x2.scalar_type());
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dy2, wc).view(ctx->saved_data["xshape"].toIntVector());
-    Tensor dw = gemm_dw(dy2, x2);
-    const auto w_dt = st_of(ctx->saved_data["w_dt"]);
-    if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int yr = (hint.group >= 0 && deferring()) ? find_role(hint, ROLE_DY, dy2) : -1;
+    Tensor dw;
+    if (yr >= 0) {
+      dw = arena_slot(hint, ROLE_DW + yr, wc.sizes(), wc.options());
+      park_gemm(hint, yr, x2, dy2, dw);
+    } else {
+      dw = gemm_dw(dy2, x2);
+      const auto w_dt = st_of(ctx->saved_data["w_dt"]);
+      if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
+    }
     Tensor db;
     const int64_t bk = ctx->saved_data["b_dt"].toInt();
     if (bk >= 0) db = colsum(dy2, (at::ScalarType)bk);
@@ -727,11 +784,14 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     // under an arena hint (a block of a run of identical blocks): the GELU output = pwconv2's input goes to slot idx of the stage arena,
     // and the backward defers dW when this node's own input already sits in its arena (written there by the hinted LayerNorm)
     const Hint hint = t_hint;
+    const int out_role = take_out_role();
     const bool ar = hinted(hint, dt) && w.scalar_type() == dt;
-    Tensor h = ar ? arena_slot(hint, ROLE_X2, with_last(x, w.size(0)), pre.options()) : at::empty(with_last(x, w.size(0)), pre.options());
+    Tensor h = (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, with_last(x, w.size(0)), pre.options())
+                                     : at::empty(with_last(x, w.size(0)), pre.options());
     Tensor h2 = h.view({-1, w.size(0)});
     at::gelu_out(h2, pre);
-    ctx->saved_data["hint"] = hint_iv(ar && in_arena(hint, ROLE_X1, x2) ? hint : Hint{});
+    const int xr = ar ? find_role(hint, ROLE_X, x2) : -1;
+    ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
     ctx->save_for_backward({x2, wc, pre});
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_dt"] = st_id(w);
@@ -745,8 +805,9 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor dh = as_rows(g[0], pre.scalar_type());
     const int64_t rows = pre.size(0), C = pre.size(1);
     const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int xr = role_of(ctx->saved_data["hint"], 0);
     const bool ar = hint.group >= 0 && deferring();
-    Tensor dpre = ar ? arena_slot(hint, ROLE_DY1, pre.sizes(), pre.options()) : at::empty_like(pre);
+    Tensor dpre = ar ? arena_slot(hint, ROLE_DY + xr, pre.sizes(), pre.options()) : at::empty_like(pre);
     Tensor db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, pre.options().dtype(at::kFloat));
     if (deferring()) {
@@ -762,8 +823,8 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
     Tensor dw;
     if (ar) {
-      dw = arena_slot(hint, ROLE_DW1, wc.sizes(), wc.options());
-      park_gemm(hint, 0, x2, dpre, dw);
+      dw = arena_slot(hint, ROLE_DW + xr, wc.sizes(), wc.options());
+      park_gemm(hint, xr, x2, dpre, dw);
     } else {
       dw = gemm_dw(dpre, x2);
       const auto w_dt = st_of(ctx->saved_data["w_dt"]);
@@ -793,7 +854,8 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
                                   out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
     ctx->save_for_backward({h2, wc, y, s, g32});
     const Hint hint = t_hint;
-    ctx->saved_data["hint"] = hint_iv(hinted(hint, dt) && w.scalar_type() == dt && in_arena(hint, ROLE_X2, h2) ? hint : Hint{});
+    const int xr = (hinted(hint, dt) && w.scalar_type() == dt) ? find_role(hint, ROLE_X, h2) : -1;
+    ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
     ctx->saved_data["hshape"] = h.sizes().vec();
     ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, st_id(w), st_id(b), has_g ? st_id(*gamma_) : (int64_t)at::kFloat,
                                                    h.requires_grad(), B};
@@ -809,8 +871,9 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
     const int64_t rows = y.size(0), C = y.size(1), B = m[6];
     const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int xr = role_of(ctx->saved_data["hint"], 0);
     const bool ar = hint.group >= 0 && deferring();
-    Tensor dy = ar ? arena_slot(hint, ROLE_DY2, y.sizes(), y.options()) : at::empty_like(y);
+    Tensor dy = ar ? arena_slot(hint, ROLE_DY + xr, y.sizes(), y.options()) : at::empty_like(y);
     Tensor db = at::empty({C}, y.options().dtype(b_dt));
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, y.options().dtype(at::kFloat));
@@ -830,8 +893,8 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
     Tensor dw;
     if (ar) {
-      dw = arena_slot(hint, ROLE_DW2, wc.sizes(), wc.options());
-      park_gemm(hint, 1, h2, dy, dw);
+      dw = arena_slot(hint, ROLE_DW + xr, wc.sizes(), wc.options());
+      park_gemm(hint, xr, h2, dy, dw);
     } else {
       dw = gemm_dw(dy, h2);
       if (dw.scalar_type() != w_dt) dw = dw.to(w_dt);
@@ -1075,6 +1138,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("pending_reductions() -> int", &pending_reductions);
   m.def("set_shared_deferral(bool on) -> ()", &set_shared_deferral);
   m.def("arena_hint(int group, int idx, int count) -> ()", &arena_hint);
+  m.def("arena_roles(int out, int grad_a, int grad_b) -> ()", &arena_roles);
   m.def("arena_release(int group) -> ()", &arena_release);
   m.def("arena_bytes() -> int", &arena_bytes);
 }

@@ -184,16 +184,20 @@ class Attention(nn.Module):
     def forward(self, x, H, W):
         return self.proj(self.core(x, H, W))
 
-    def core(self, x, H, W):
-        """Everything up to (not including) the output projection; Block fuses the projection with its residual epilogue."""
+    def core(self, x, H, W, run=ops.NO_RUN):
+        """Everything up to (not including) the output projection; Block fuses the projection with its residual epilogue.
+        Deferred Linears of a Block (ops.block_run): 0 = q, 1 = kv, 2 = proj, 3 = fc1, 4 = fc2."""
         q = self.q(x)
         if self.sr_ratio > 1:  # k == s conv == patchify + GEMM, stays token-major
             w, b = wb(self.sr)
             r = ops.linear(_patchify(x, H, W, self.sr_ratio), w.flatten(1), b)
+            run.roles(out=1)                      # the reduced tokens after their LayerNorm = input of kv
             r = self.norm(r)
         else:
-            r = x
-        return ops.sra_attention(q, self.kv(r), self.num_heads, self.scale)
+            r = x                                 # kv reads the same arena slot as q
+        kv = self.kv(r)
+        run.roles(out=2, grad_a=0, grad_b=1)      # attention output = input of proj; its backward produces d(q out) and d(kv out)
+        return ops.sra_attention(q, kv, self.num_heads, self.scale)
 
 
 class DWConv(nn.Module):
@@ -223,8 +227,10 @@ class Mlp(nn.Module):
     def forward(self, x, H, W):
         return self.fc2(self.hidden(x, H, W))
 
-    def hidden(self, x, H, W):
-        return self.dwconv(self.fc1(x), H, W, gelu=True)  # dw3x3 + bias + exact GELU in one pass
+    def hidden(self, x, H, W, run=ops.NO_RUN):
+        h = self.fc1(x)
+        run.roles(out=4, grad_a=3)                # dw3x3 output = input of fc2; its backward produces d(fc1 out)
+        return self.dwconv(h, H, W, gelu=True)    # dw3x3 + bias + exact GELU in one pass
 
 
 class Block(nn.Module):
@@ -244,12 +250,14 @@ class Block(nn.Module):
     def _scale(self, x):
         return self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, run=ops.NO_RUN):
         if _USE["fused_linear"] and x.is_cuda:   # projection / fc2 + DropPath + residual as one node (bias gradient fused in its backward)
+            run.roles(out=0)                      # norm1 output = input of q (and of kv without spatial reduction)
             v, xs = self.norm1.fork(x) if _USE["ln_fork"] else (self.norm1(x), x)
-            x = ops.linear_residual(self.attn.core(v, H, W), *wb(self.attn.proj), xs, self._scale(x))
+            x = ops.linear_residual(self.attn.core(v, H, W, run), *wb(self.attn.proj), xs, self._scale(x))
+            run.roles(out=3)                      # norm2 output = input of fc1
             v, xs = self.norm2.fork(x) if _USE["ln_fork"] else (self.norm2(x), x)
-            return ops.linear_residual(self.mlp.hidden(v, H, W), *wb(self.mlp.fc2), xs, self._scale(x))
+            return ops.linear_residual(self.mlp.hidden(v, H, W, run), *wb(self.mlp.fc2), xs, self._scale(x))
         x = ops.scale_residual(x, self.attn(self.norm1(x), H, W), self._scale(x))   # x + DropPath(attn), one pass
         return ops.scale_residual(x, self.mlp(self.norm2(x), H, W), self._scale(x))
 
@@ -267,11 +275,14 @@ class convnext_Block(nn.Module):
         self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, run=ops.NO_RUN):
         s = self.drop_path.scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
         if _USE["fused_linear"] and x.is_cuda:   # pwconv1+GELU and pwconv2+gamma+DropPath+residual as two nodes with fused backward passes
             y, xs = ops.dwconv_fork(x, *wb(self.dwconv)) if _USE["ln_fork"] else (ops.dwconv_nhwc(x, *wb(self.dwconv)), x)
-            h = ops.linear_gelu(self.norm(y), *wb(self.pwconv1))
+            run.roles(out=0)                      # LayerNorm output = input of pwconv1 (deferred Linear 0 of the block)
+            y = self.norm(y)
+            run.roles(out=1)                      # GELU output = input of pwconv2 (deferred Linear 1)
+            h = ops.linear_gelu(y, *wb(self.pwconv1))
             return ops.linear_residual(h, *wb(self.pwconv2), xs, s, self.gamma)
         y = ops.dwconv_nhwc(x, *wb(self.dwconv))
         y = self.pwconv2(F.gelu(self.pwconv1(self.norm(y))))
@@ -319,7 +330,7 @@ class ShapePropEncoder(nn.Module):
             with ops.block_run(self, i, len(self.stages[i]), t4) as run:     # identical blocks: their weight-gradient GEMMs batch
                 for j, blk in enumerate(self.stages[i]):
                     run.at(j)
-                    t4 = blk.forward_nhwc(t4)
+                    t4 = blk.forward_nhwc(t4, run)
             t = t4.reshape(B, h * w, -1)
             outs.append((t, h, w))
         size = (outs[0][1], outs[0][2])
@@ -538,8 +549,11 @@ class PyramidVisionTransformerImpr(nn.Module):
             d = self.prompt_decoder[i].depth
             prompts = self.prompt_decoder[i].forward_tokens(embedding3, H, W, None if trunks is None else trunks[off:off + d])
             off += d                                                            # prompts: already at (H, W), already tokens
-            for j, blk in enumerate(getattr(self, f"block{i + 1}")):
-                x = blk(x + prompts[j], H, W)
+            blocks = getattr(self, f"block{i + 1}")
+            with ops.block_run(self, i, len(blocks), x) as run:                 # identical blocks: their weight-gradient GEMMs batch
+                for j, blk in enumerate(blocks):
+                    run.at(j)
+                    x = blk(x + prompts[j], H, W, run)
             x = getattr(self, f"norm{i + 1}")(x)
             x = _tokens_to_nchw(x, H, W)   # channels_last view: feeds the next patch embed and the Hitnet decoder as is
             outs.append(x)

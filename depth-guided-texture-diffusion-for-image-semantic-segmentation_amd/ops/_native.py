@@ -79,7 +79,24 @@ class block_run:
         if self.nat is not None:
             self.nat.arena_hint(self.group, j, self.n)
 
+    def roles(self, out: int = -1, grad_a: int = -1, grad_b: int = -1) -> None:
+        """The NEXT arena-capable node writes its forward output as the input X[out] of the block's out-th deferred Linear, and
+        the gradients its backward produces as DY[grad_a] (, DY[grad_b]): the output gradients of those Linears."""
+        if self.nat is not None:
+            self.nat.arena_roles(out, grad_a, grad_b)
+
     def __exit__(self, *exc):
         if self.nat is not None:
             self.nat.arena_hint(-1, 0, 0)
         return False
+
+
+class _NoRun:
+    def at(self, j):
+        pass
+
+    def roles(self, out=-1, grad_a=-1, grad_b=-1):
+        pass
+
+
+NO_RUN = _NoRun()

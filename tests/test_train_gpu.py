@@ -412,9 +412,10 @@ def test_batched_weight_gradient_gemms_match_per_layer_path(dgtd):
     finally:
         N.BATCH_WGRAD = True
     assert nat.arena_bytes() == base, "arenas must die with the model"
-    assert parked[True] >= parked[False] + 2 * (3 + 3 + 27 + 3)      # one parked GEMM per pwconv of the 36 ConvNeXt blocks
-    pw = [k for k in grads[True] if ".pwconv" in k and k.endswith("weight")]
-    assert len(pw) == 72
+    # one parked GEMM per pwconv of the 36 ConvNeXt blocks and per q / kv / proj / fc1 / fc2 of the 16 PVT blocks
+    assert parked[True] >= parked[False] + 2 * (3 + 3 + 27 + 3) + 5 * (3 + 4 + 6 + 3), (parked[True], parked[False])
+    pw = [k for k in grads[True] if k.endswith("weight") and (".pwconv" in k or (".block" in k and any(t in k for t in (".attn.q.", ".attn.kv.", ".attn.proj.", ".mlp.fc1.", ".mlp.fc2."))))]
+    assert len(pw) == 72 + 80, len(pw)
     for k in pw:
         a, b = grads[True][k], grads[False][k]
         assert (a - b).norm() / b.norm() < 1e-2, k
