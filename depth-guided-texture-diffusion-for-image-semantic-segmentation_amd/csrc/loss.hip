@@ -187,7 +187,15 @@ __global__ __launch_bounds__(256) void ssim_minmax_kernel(const float* __restric
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n - 1 - threadIdx.x]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
-  if ((threadIdx.x & 63) == 0) { atomicMin(mm, f2ord(lo)); atomicMax(mm + 1, f2ord(hi)); }
+  // one atomic pair per WORKGROUP: 8192 same-address device atomics (one pair per wave of 2048 workgroups) serialised into 190 us
+  __shared__ float wl[4], wh[4];
+  if ((threadIdx.x & 63) == 0) { wl[threadIdx.x >> 6] = lo; wh[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fminf(fminf(wl[0], wl[1]), fminf(wl[2], wl[3]));
+    hi = fmaxf(fmaxf(wh[0], wh[1]), fmaxf(wh[2], wh[3]));
+    atomicMin(mm, f2ord(lo)); atomicMax(mm + 1, f2ord(hi));
+  }
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -244,7 +252,7 @@ extern "C" int dgtd_ssim_value(const float* x_hp, const float* image, float* out
   if (e == hipSuccess) e = hipMemsetAsync((char*)workspace + 4, 0, 12, st);
   if (e != hipSuccess) DGTD_FAIL(3, "ssim_value: memset failed: %s", hipGetErrorString(e));
   const long n = (long)B * C * S * S;
-  hipLaunchKernelGGL(ssim_minmax_kernel, dim3((int)std::min<long>(cdiv(n, 1024), 2048)), dim3(256), 0, st, x_hp, mm, n);
+  hipLaunchKernelGGL(ssim_minmax_kernel, dim3((int)std::min<long>(cdiv(n, 1024), 512)), dim3(256), 0, st, x_hp, mm, n);
   DGTD_CHECK_LAUNCH("ssim_minmax");
   hipLaunchKernelGGL(ssim_map_kernel, dim3((int)std::min<long>(cdiv((long)S * S, 256), 256), B * C), dim3(256), 0, st, x_hp, image, (const unsigned*)mm, acc, S);
   DGTD_CHECK_LAUNCH("ssim_map");
