@@ -4,10 +4,13 @@
 //   out[n,q,m,:] = sum_{l,p} attn[n,q,m,l,p] * bilinear(value_l[n,:,m,:], loc[n,q,m,l,p])      (zero padding, align_corners=False)
 // value [N,S,M,D] (S = sum_l H_l*W_l, level l starts at level_start[l]); spatial_shapes [L,2] = (H_l, W_l) int64;
 // loc [N,Lq,M,L,P,2] = (x, y) in [0,1]; attn [N,Lq,M,L,P]; out [N,Lq,M*D].  Pixel coordinates: h = y*H - 0.5, w = x*W - 0.5.
-// Gather-bound (HBM / L2): one thread per output channel d, the D threads of a (n,q,m) share the sampling geometry (broadcast
-// loads) and read D contiguous values per corner.  Backward: one workgroup per (n,q,m); value gradients by atomics (4 corners per
+// Gather-bound (HBM / L2).  Forward: one thread per 16 BYTES of output channels (4 fp32 / 2 fp64) when D allows it - the D/4 threads
+// of a (n,q,m) share the sampling geometry (broadcast loads) and each corner is one 16-byte load per thread, a quarter of the load
+// and address instructions of the one-channel-per-thread mapping (kept for odd D).  Backward: one workgroup per (n,q,m); value gradients by atomics (4 corners per
 // sample), the location / weight gradients need a sum over d: wave shuffle + LDS across the waves of the workgroup instead of the
-// reference's seven shared-memory reduction variants (ms_deform_im2col_cuda.cuh:302-920).
+// reference's seven shared-memory reduction variants (ms_deform_im2col_cuda.cuh:302-920).  The backward deliberately keeps one
+// channel per lane: the atomic units work per 128-byte line and instruction, and D consecutive lanes cover each corner's line with ONE
+// atomic instruction; a 4-channels-per-lane variant (8 triples per wave) issued 4x the line requests and ran 3.5x slower (measured).
 #include "common.h"
 
 namespace {
@@ -57,6 +60,45 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const S* __restrict__ val
       }
     }
     out[i] = acc;
+  }
+}
+
+// V channels per thread (V * sizeof(S) == 16): same sampling arithmetic, vector corner loads
+template <typename S, int V>
+__global__ __launch_bounds__(256) void msda_fwd_vec_kernel(const S* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lstart, const S* __restrict__ loc,
+                                                           const S* __restrict__ attn, S* __restrict__ out, int N, int Sv, int M, int D,
+                                                           int L, int Lq, int P) {
+  typedef S vec __attribute__((ext_vector_type(V)));
+  const int DG = D / V;
+  const int64_t total = (int64_t)N * Lq * M * DG;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % DG) * V;
+    const int64_t r = i / DG;                // (n, q, m) flattened
+    const int m = (int)(r % M);
+    const int n = (int)((r / M) / Lq);
+    const S* vb = value + ((size_t)n * Sv * M + m) * D + d;
+    const S* lp = loc + (size_t)r * L * P * 2;
+    const S* ap = attn + (size_t)r * L * P;
+    const size_t rs = (size_t)M * D;
+    vec acc = (vec)(S)0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const S* vl = vb + (size_t)lstart[l] * rs;
+      for (int p = 0; p < P; ++p) {
+        const Geom<S> g = geom<S>(lp[(l * P + p) * 2], lp[(l * P + p) * 2 + 1], H, W);
+        if (!g.ok) continue;
+        const vec zero = (vec)(S)0;
+        const S* c00 = vl + ((size_t)g.h0 * W + g.w0) * rs;
+        const vec v00 = g.in00 ? *reinterpret_cast<const vec*>(c00) : zero, v01 = g.in01 ? *reinterpret_cast<const vec*>(c00 + rs) : zero;
+        const vec v10 = g.in10 ? *reinterpret_cast<const vec*>(c00 + (size_t)W * rs) : zero;
+        const vec v11 = g.in11 ? *reinterpret_cast<const vec*>(c00 + (size_t)W * rs + rs) : zero;
+        // same association as the scalar kernel: (1-lh)*((1-lw)*v00 + lw*v01) + lh*((1-lw)*v10 + lw*v11)
+        const vec s = ((S)1 - g.lh) * (((S)1 - g.lw) * v00 + g.lw * v01) + g.lh * (((S)1 - g.lw) * v10 + g.lw * v11);
+        acc += ap[l * P + p] * s;
+      }
+    }
+    *reinterpret_cast<vec*>(out + r * D + d) = acc;
   }
 }
 
@@ -131,6 +173,15 @@ extern "C" int dgtd_ms_deform_attn_fwd(const void* value, const int64_t* spatial
                                        int Lq, int P, dgtd_dtype dt, dgtd_stream s) {
   DGTD_PROF(s, DGTD_HBM, (double)dgtd_esize(dt) * N * Lq * M * D * (4.0 * L * P + 1), "dgtd_ms_deform_attn_fwd[N=%d,Lq=%d,M=%d,D=%d,L=%d,P=%d]", N, Lq, M, D, L, P);
   DGTD_REQUIRE(check_sizes(N, S, M, D, L, Lq, P), "ms_deform_attn_fwd: bad sizes");
+  const int V = dt == DGTD_F32 ? 4 : 2;
+  if ((dt == DGTD_F32 || dt == DGTD_F64) && D % V == 0 && ((uintptr_t)value % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    const int64_t vtotal = (int64_t)N * Lq * M * (D / V);
+    const int vgrid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vtotal, 256), 65536));
+    if (dt == DGTD_F32) hipLaunchKernelGGL((msda_fwd_vec_kernel<float, 4>), dim3(vgrid), dim3(256), 0, (hipStream_t)s, (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc, (const float*)attn_weight, (float*)out, N, S, M, D, L, Lq, P);
+    else hipLaunchKernelGGL((msda_fwd_vec_kernel<double, 2>), dim3(vgrid), dim3(256), 0, (hipStream_t)s, (const double*)value, spatial_shapes, level_start_index, (const double*)sampling_loc, (const double*)attn_weight, (double*)out, N, S, M, D, L, Lq, P);
+    DGTD_CHECK_LAUNCH("ms_deform_attn_fwd");
+    return 0;
+  }
   const int64_t total = (int64_t)N * Lq * M * D;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 65536));
   if (dt == DGTD_F32) hipLaunchKernelGGL(msda_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc, (const float*)attn_weight, (float*)out, N, S, M, D, L, Lq, P);

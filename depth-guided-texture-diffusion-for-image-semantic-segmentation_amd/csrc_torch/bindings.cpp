@@ -210,6 +210,7 @@ static std::vector<PendingConv> g_pending_conv;
 // the one PReLU slope shared by every activation of the decoder (cod.py:686): all backward calls of a step add into ONE fp32 accumulator
 // (first call: zeroed here and handed to autograd through a parked 1x1 "reduction" that converts it; later calls return nothing)
 static std::map<const void*, Tensor> g_prelu_acc;
+static std::map<const void*, Tensor> g_conv_flip;        // weight -> its flipped copy, valid for one step (cleared at every flush)
 
 // Deferrals that hand ONE gradient tensor to autograd for several calls are only sound when nothing is flushed between the first and
 // the last of those calls: the reducer switches them off when it gathers buckets from inside the backward pass (eager overlap mode).
@@ -298,6 +299,7 @@ void flush_deferred() {
       convs.swap(g_pending_conv);
       dest.swap(g_conv_dest);
       g_prelu_acc.clear();
+      g_conv_flip.clear();
     }
     if (!convs.empty()) flush_convs(convs, dest);
   }
@@ -356,6 +358,7 @@ void set_deferred(bool on) {
     g_conv_dest.clear();
     g_conv_seen.clear();
     g_prelu_acc.clear();
+    g_conv_flip.clear();
   } else {
     flush_deferred();
   }
@@ -912,8 +915,23 @@ inline void conv3x3_backward_raw(const Tensor& x, const Tensor& w, const Tensor&
                                  bool has_b, Tensor& dx, Tensor& dw, Tensor& db, bool skip_wgrad = false) {
   const void* mask = y_mask.defined() ? y_mask.data_ptr() : nullptr;
   if (need_dx) {
-    Tensor wt = at::empty({g.Z, g.Ci, 3, 3, g.Co}, w.options());
-    check(dgtd_conv3x3_flip(w.data_ptr(), wt.data_ptr(), g.Z, g.Co, g.Ci, stream()), "dgtd_conv3x3_flip");
+    // the transposed + flipped kernel of the input-gradient convolution: a module called several times per step (CABs of the decoder
+    // iterations) flips the same weight every time - under deferral (one step = one set of weight values) the first flip is kept
+    Tensor wt;
+    const bool cache = deferring() && g.Z == 1;
+    if (cache) {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      auto it = g_conv_flip.find(w.data_ptr());
+      if (it != g_conv_flip.end()) wt = it->second;
+    }
+    if (!wt.defined()) {
+      wt = at::empty({g.Z, g.Ci, 3, 3, g.Co}, w.options());
+      check(dgtd_conv3x3_flip(w.data_ptr(), wt.data_ptr(), g.Z, g.Co, g.Ci, stream()), "dgtd_conv3x3_flip");
+      if (cache) {
+        std::lock_guard<std::mutex> lk(g_pending_mu);
+        g_conv_flip.emplace(w.data_ptr(), wt);
+      }
+    }
     check(dgtd_conv3x3_fwd(dy.data_ptr(), mask, wt.data_ptr(), nullptr, dx.data_ptr(), g.Z, g.B, g.H, g.W, g.Co, g.Ci, 0, 0, code(dy), stream()),
           "dgtd_conv3x3_fwd (input gradient)");
   }

@@ -65,7 +65,7 @@ def test_hip_forward_backward_vs_oracle(name, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025])
+@pytest.mark.parametrize("channels", [4, 16, 30, 32, 64, 71, 128, 256, 512, 1025])
 def test_hip_gradients_by_channel_count(channels):
     """twig/ops/test.py:108 sweeps the channel count through the backward's reduction variants; here one kernel covers them."""
     import dgtd
