@@ -40,6 +40,7 @@ SIGNATURES = {
     "dgtd_dwconv_bwd_weight_partial": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), _vp]),
     "dgtd_dwconv_bwd_weight_batched_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
     "dgtd_dwconv_bwd_weight_batched": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_dwconv_pack_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dgtd_dwconv_pack": (_i, [_vp, _vp, _fp, _i, _i, _i, _vp]),
     "dgtd_dwconv_unpack_grads": (_i, [_fp, _vp, _vp, _i, _i, _i, _vp]),
     "dgtd_scale_residual_fwd": (_i, [_vp, _vp, _fp, _fp, _vp, _i64, _i, _i64, _i, _vp]),

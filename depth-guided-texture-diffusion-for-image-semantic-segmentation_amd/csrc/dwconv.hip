@@ -471,6 +471,26 @@ __global__ __launch_bounds__(256) void dwconv_pack_kernel(const T* __restrict__ 
   if (i < C) packed[(size_t)2 * KK * C + i] = bias ? (float)bias[i] : 0.f;
 }
 
+// the same packing for up to PK_MAX layers in one launch (weights only change between steps: all layers are re-packed together at the
+// start of a step instead of one 5 us launch in front of every depthwise convolution)
+constexpr int PK_MAX = 64;
+struct PackTable { const void* w[PK_MAX]; const void* b[PK_MAX]; float* out[PK_MAX]; int C[PK_MAX]; int KK[PK_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_pack_batched_kernel(PackTable t) {
+  const int e = blockIdx.y, C = t.C[e], KK = t.KK[e];
+  const int i = blockIdx.x * 256 + threadIdx.x;   // i = tap * C + c
+  const T* __restrict__ w = (const T*)t.w[e];
+  const T* __restrict__ bias = (const T*)t.b[e];
+  float* __restrict__ packed = t.out[e];
+  if (i < KK * C) {
+    const int tap = i / C, c = i % C;
+    const float v = (float)w[(size_t)c * KK + tap];
+    packed[i] = v;
+    packed[(size_t)KK * C + (size_t)(KK - 1 - tap) * C + c] = v;
+  }
+  if (i < C) packed[(size_t)2 * KK * C + i] = bias ? (float)bias[i] : 0.f;
+}
+
 // grads fp32 [ dwt (K*K x C) | db (C) ] -> dweight [C, K*K] and dbias [C] in dtype T
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_unpack_kernel(const float* __restrict__ g, T* __restrict__ dw,
@@ -665,6 +685,29 @@ extern "C" int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, 
   else if (wdt == DGTD_F32) hipLaunchKernelGGL(dwconv_pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)w, (const float*)bias, packed, C, KK);
   else DGTD_FAIL(2, "dwconv_pack: bad dtype %d", (int)wdt);
   DGTD_CHECK_LAUNCH("dwconv_pack");
+  return 0;
+}
+
+extern "C" int dgtd_dwconv_pack_batched(const void* const* w, const void* const* bias, float* const* packed, const int* C, const int* K, int n,
+                                        dgtd_dtype wdt, dgtd_stream s) {
+  DGTD_REQUIRE(n > 0 && w && packed && C && K, "dwconv_pack_batched: no layers");
+  DGTD_REQUIRE(DGTD_IS_HALF(wdt) || wdt == DGTD_F32, "dwconv_pack_batched: bad dtype %d", (int)wdt);
+  for (int z0 = 0; z0 < n; z0 += PK_MAX) {
+    const int m = std::min(PK_MAX, n - z0);
+    PackTable t;
+    int most = 0;
+    for (int i = 0; i < PK_MAX; ++i) {
+      const int j = z0 + (i < m ? i : 0);
+      DGTD_REQUIRE(w[j] && packed[j] && C[j] > 0 && (K[j] == 3 || K[j] == 7), "dwconv_pack_batched: bad layer %d (C=%d K=%d)", j, C[j], K[j]);
+      t.w[i] = w[j]; t.b[i] = bias ? bias[j] : nullptr; t.out[i] = packed[j]; t.C[i] = C[j]; t.KK[i] = K[j] * K[j];
+      most = std::max(most, t.KK[i] * t.C[i]);
+    }
+    const dim3 grid((unsigned)cdiv(most, 256), (unsigned)m);
+    if (wdt == DGTD_BF16) hipLaunchKernelGGL(dwconv_pack_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, t);
+    else if (wdt == DGTD_F16) hipLaunchKernelGGL(dwconv_pack_batched_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, t);
+    else hipLaunchKernelGGL(dwconv_pack_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, t);
+    DGTD_CHECK_LAUNCH("dwconv_pack_batched");
+  }
   return 0;
 }
 

@@ -348,6 +348,62 @@ void flush_deferred() {
   }
   check(dgtd_multi_reduce(es.data(), (int)es.size(), stream()), "dgtd_multi_reduce");
 }
+// PREPARED WEIGHTS: the packed fp32 form { w_t | w_t flipped | bias } every depthwise convolution computes from.  Weights change
+// only between steps, so under the reducer a layer packs itself once (first step) into a PERSISTENT buffer and registers it; from
+// then on set_deferred(true) - the start of every step - re-packs all registered layers in one launch (52 launches -> 1 per step).
+// Entries die with the weight's storage (weak reference); outside zero_grad() .. finish() the nodes pack on the fly as before.
+struct PreparedDw { c10::weak_intrusive_ptr<c10::StorageImpl> wstore; const void* w; const void* b; Tensor packed; int C, K; at::ScalarType dt; };
+static std::map<const void*, PreparedDw> g_prepared_dw;
+inline bool prepare_on() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_PREPARE_WEIGHTS"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+static void refresh_prepared() {
+  std::map<int, std::vector<PreparedDw*>> by_dt;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    for (auto it = g_prepared_dw.begin(); it != g_prepared_dw.end();) {
+      if (it->second.wstore.expired()) it = g_prepared_dw.erase(it);
+      else { by_dt[(int)it->second.dt].push_back(&it->second); ++it; }
+    }
+  }
+  for (auto& kv : by_dt) {
+    std::vector<const void*> ws, bs;
+    std::vector<float*> outs;
+    std::vector<int> Cs, Ks;
+    for (auto* p : kv.second) { ws.push_back(p->w); bs.push_back(p->b); outs.push_back(p->packed.data_ptr<float>()); Cs.push_back(p->C); Ks.push_back(p->K); }
+    const dgtd_dtype dt = kv.first == (int)at::kFloat ? DGTD_F32 : (kv.first == (int)at::kBFloat16 ? DGTD_BF16 : DGTD_F16);
+    check(dgtd_dwconv_pack_batched(ws.data(), bs.data(), outs.data(), Cs.data(), Ks.data(), (int)ws.size(), dt, stream()), "dgtd_dwconv_pack_batched");
+  }
+}
+// the packed weights of (weight, bias) for this step: the registered buffer (already refreshed), or a fresh pack that is registered
+inline Tensor packed_dw(const Tensor& weight, const Tensor& bias, bool has_bias, int64_t C, int64_t K) {
+  const int64_t KK = K * K;
+  const bool use = deferring() && prepare_on() && weight.has_storage();
+  if (use) {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    auto it = g_prepared_dw.find(weight.data_ptr());
+    if (it != g_prepared_dw.end()) {
+      PreparedDw& p = it->second;
+      auto st = p.wstore.lock();
+      if (st && st.get() == weight.storage().unsafeGetStorageImpl() && p.C == C && p.K == K && p.dt == weight.scalar_type() &&
+          p.b == (has_bias ? bias.data_ptr() : nullptr) && p.packed.device() == weight.device())
+        return p.packed;
+      g_prepared_dw.erase(it);
+    }
+  }
+  Tensor packed = at::empty({(2 * KK + 1) * C}, weight.options().dtype(at::kFloat));   // { w_t | w_t flipped | bias }
+  check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight), stream()),
+        "dgtd_dwconv_pack");
+  if (use) {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    g_prepared_dw.emplace(weight.data_ptr(),
+                          PreparedDw{c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(weight.storage().unsafeGetStorageImpl())),
+                                     weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed, (int)C, (int)K, weight.scalar_type()});
+  }
+  return packed;
+}
+
 void set_deferred(bool on) {
   if (on) {   // entries left over from a backward that was never flushed point at dead memory: drop them
     std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -363,6 +419,7 @@ void set_deferred(bool on) {
     flush_deferred();
   }
   g_defer.store(on);
+  if (on && prepare_on()) refresh_prepared();
 }
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -534,9 +591,7 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     TORCH_CHECK(x.size(3) == C && weight.size(1) == 1, "dwconv_nhwc: bad shapes");
     Tensor bias = has_bias ? bias_->contiguous() : Tensor();
     if (has_bias) TORCH_CHECK(bias.scalar_type() == weight.scalar_type(), "dwconv_nhwc: weight/bias dtype mismatch");
-    Tensor packed = at::empty({(2 * KK + 1) * C}, x.options().dtype(at::kFloat));   // { w_t | w_t flipped | bias }
-    check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight),
-                           stream()), "dgtd_dwconv_pack");
+    Tensor packed = packed_dw(weight, bias, has_bias, C, K);                        // { w_t | w_t flipped | bias }
     const float* base = packed.data_ptr<float>();
     const Hint hint = t_hint;
     const int out_role = take_out_role();
@@ -584,9 +639,7 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     const bool has_bias = bias_.has_value() && bias_->defined();
     TORCH_CHECK(x.size(3) == C && weight.size(1) == 1, "dwconv_nhwc: bad shapes");
     Tensor bias = has_bias ? bias_->contiguous() : Tensor();
-    Tensor packed = at::empty({(2 * KK + 1) * C}, x.options().dtype(at::kFloat));
-    check(dgtd_dwconv_pack(weight.data_ptr(), has_bias ? bias.data_ptr() : nullptr, packed.data_ptr<float>(), (int)C, (int)K, code(weight),
-                           stream()), "dgtd_dwconv_pack");
+    Tensor packed = packed_dw(weight, bias, has_bias, C, K);
     const float* base = packed.data_ptr<float>();
     Tensor y = DwConvFn::launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, 0, (int)K);
     ctx->save_for_backward({x, packed});

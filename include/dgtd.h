@@ -92,6 +92,10 @@ int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bias, const vo
 /* Conv2d-layout parameters -> kernel layout, one launch: w [C,1,K,K] and bias [C] (dtype wdt; bias may be NULL)
  * -> packed fp32 [(2*K*K + 1) * C] = { w_t | w_t spatially flipped (for the backward w.r.t. x) | bias }.      */
 int dgtd_dwconv_pack(const void* w, const void* bias, float* packed, int C, int K, dgtd_dtype wdt, dgtd_stream s);
+/* The same packing for n layers in one launch (HOST arrays of n; bias: NULL or n pointers, entries may be NULL): weights change only
+ * between optimizer steps, so a training step re-packs every depthwise layer once, together.                                      */
+int dgtd_dwconv_pack_batched(const void* const* w, const void* const* bias, float* const* packed, const int* C, const int* K, int n,
+                             dgtd_dtype wdt, dgtd_stream s);
 /* grads fp32 [(K*K + 1) * C] = { dw_t | db } -> dw [C,1,K,K], db [C] in dtype wdt (db may be NULL).           */
 int dgtd_dwconv_unpack_grads(const float* grads, void* dw, void* db, int C, int K, dgtd_dtype wdt, dgtd_stream s);
 /* grads fp32 [(K*K + 1) * C] = { dw_t | db } is OVERWRITTEN (db = 0 when has_bias == 0); C % 128 == 0.

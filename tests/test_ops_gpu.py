@@ -575,6 +575,41 @@ def test_conv3x3_weight_gradients_deferred_batched_and_shared(dgtd, half):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
+def test_dwconv_prepared_weights_follow_the_parameters(dgtd, dtype):
+    """Under deferral a depthwise layer packs its weights once into a persistent buffer and every later step start re-packs all registered
+    layers in one launch: the outputs must follow in-place weight updates between steps (the optimizer), a bias that appears, and a NEW
+    weight tensor that reuses the address of a freed one."""
+    nat = dgtd.ops._native.ops()
+    if nat is None:
+        pytest.skip("prepared weights live in the C++ binding layer")
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+
+    def ref(x, w, b):
+        return F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None if b is None else b.float(), padding=w.shape[-1] // 2, groups=w.shape[0]).permute(0, 2, 3, 1)
+
+    def step(x, w, b):
+        nat.set_deferred(True)                      # = reducer.zero_grad(): refreshes every registered layer
+        try:
+            return dgtd.ops.dwconv_nhwc(x, w, b, False)
+        finally:
+            nat.set_deferred(False)
+
+    for K, C in ((7, 128), (3, 256)):
+        x = _rand(2, 12, 12, C, seed=1, dtype=dtype)
+        w = (_rand(C, 1, K, K, seed=2) / K).to(dtype).requires_grad_()
+        b = (0.1 * _rand(C, seed=3)).to(dtype).requires_grad_()
+        for it in range(3):
+            torch.testing.assert_close(step(x, w, b).float(), ref(x, w, b), atol=tol, rtol=tol)
+            with torch.no_grad():                   # what the optimizer does between steps
+                w.mul_(-1.5); b.add_(0.25)
+        torch.testing.assert_close(step(x, w, None).float(), ref(x, w, None), atol=tol, rtol=tol)      # same weight, now without bias
+        ptr = w.data_ptr()
+        del w
+        w2 = (_rand(C, 1, K, K, seed=9) / K).to(dtype).requires_grad_()                                 # usually lands on the freed address
+        torch.testing.assert_close(step(x, w2, b).float(), ref(x, w2, b), atol=tol, rtol=tol), ptr
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
 def test_prelu_shared_slope_gradient_under_deferral(dgtd, dtype):
     """One nn.PReLU() slope shared by every activation (cod.py:686): under deferral all backward calls add into one fp32 accumulator
     and autograd receives a single gradient, converted at the flush.  Against fp32 torch.prelu summed over the calls; with shared
