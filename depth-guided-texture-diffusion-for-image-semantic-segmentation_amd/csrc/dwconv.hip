@@ -126,6 +126,106 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   }
 }
 
+// 3x3, sliding window down the image: a thread owns a strip of TX = 4 x-positions x V = 4 channels and walks RY output rows; the
+// three input rows of the window live in registers as floats and every input row is loaded (and converted) ONCE per thread - the
+// strip kernel above fetches it once per output row, i.e. three times, and re-reads the 9 x V weights per strip (here: registers).
+// Same modes as dwconv_fwd_kernel.  Lanes run along C (64 lanes x 8 B = 512 B contiguous per pixel).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void dwconv3_sw_kernel(const T* __restrict__ x, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, const T* __restrict__ aux,
+                                                         T* __restrict__ y, int B, int H, int W, int C, int RY) {
+  constexpr int V = 4, TX = 4, K = 3, NI = TX + K - 1;
+  typedef typename VecN<T, V>::type VT;
+  typedef float f32v __attribute__((ext_vector_type(V)));
+  const int CV = C / V, XB = (W + TX - 1) / TX, YC = (H + RY - 1) / RY;
+  const int64_t total = (int64_t)B * YC * XB * CV;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cv = (int)(gid % CV);
+  int64_t r = gid / CV;
+  const int xb = (int)(r % XB); r /= XB;
+  const int yc = (int)(r % YC);
+  const int b = (int)(r / YC);
+  const int x0 = xb * TX, c0 = cv * V, y_begin = yc * RY, y_end = min(H, y_begin + RY);
+  f32v w[K * K], bv = (f32v)0.f;
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) w[t] = *reinterpret_cast<const f32v*>(wt + (size_t)t * C + c0);
+  if (bias) bv = *reinterpret_cast<const f32v*>(bias + c0);
+  const T* xb_ = x + (size_t)b * H * W * C + c0;
+  auto load_row = [&](int yy, VT* dst) {                       // input row yy (zeros outside the image), columns x0-1 .. x0+TX
+    const bool rowok = yy >= 0 && yy < H;
+    const T* row = xb_ + (size_t)(rowok ? yy : 0) * W * C;
+    VT z;
+#pragma unroll
+    for (int j = 0; j < V; ++j) z[j] = (T)0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int xx = x0 + i - 1;
+      dst[i] = (rowok && xx >= 0 && xx < W) ? *reinterpret_cast<const VT*>(row + (size_t)xx * C) : z;
+    }
+  };
+  auto cvt = [&](const VT* raw, f32v* dst) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < V; ++j) dst[i][j] = (float)raw[i][j];
+  };
+  f32v r0[NI], r1[NI], r2[NI];                                   // rows y-1, y, y+1 of the window
+  VT raw[NI];
+  load_row(y_begin - 1, raw); cvt(raw, r0);
+  load_row(y_begin, raw); cvt(raw, r1);
+  load_row(y_begin + 1, raw);
+  for (int yy = y_begin; yy < y_end; ++yy) {
+    cvt(raw, r2);
+    if (yy + 1 < y_end) load_row(yy + 2, raw);                  // in flight during the arithmetic of this row
+    VT g[TX];
+    if (MODE >= 2) {
+#pragma unroll
+      for (int t = 0; t < TX; ++t)
+        if (x0 + t < W) g[t] = *reinterpret_cast<const VT*>(aux + (((size_t)b * H + yy) * W + x0 + t) * C + c0);
+    }
+    T* orow = y + (((size_t)b * H + yy) * W) * C + c0;
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+      f32v acc = bv;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        acc = __builtin_elementwise_fma(r0[t + kx], w[kx], acc);
+        acc = __builtin_elementwise_fma(r1[t + kx], w[K + kx], acc);
+        acc = __builtin_elementwise_fma(r2[t + kx], w[2 * K + kx], acc);
+      }
+      if (x0 + t < W) {
+        VT o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          float v = acc[j];
+          if (MODE == 1) v = gelu_f(v);
+          else if (MODE == 2) v = (float)g[t][j] * gelu_grad_f(v);
+          else if (MODE == 3) v = v + (float)g[t][j];
+          o[j] = (T)v;
+        }
+        *reinterpret_cast<VT*>(orow + (size_t)(x0 + t) * C) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { r0[i] = r1[i]; r1[i] = r2[i]; }
+  }
+}
+
+template <typename T>
+int fwd3_sw_launch(const void* x, const float* wt, const float* bias, const void* aux, void* y, int B, int H, int W, int C, int mode, hipStream_t s) {
+  // rows per thread: long enough to amortise the two halo rows, short enough for >= ~16 waves per CU
+  int RY = 32;
+  while (RY > 8 && (int64_t)B * cdiv(H, RY) * cdiv(W, 4) * (C / 4) < (int64_t)256 * 16 * 64) RY /= 2;
+  const int64_t total = (int64_t)B * cdiv(H, RY) * cdiv(W, 4) * (C / 4);
+  const dim3 grid((unsigned)cdiv(total, 256));
+#define DW3_LAUNCH(MODE) hipLaunchKernelGGL((dwconv3_sw_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, wt, bias, (const T*)aux, (T*)y, B, H, W, C, RY)
+  if (mode == 0) DW3_LAUNCH(0); else if (mode == 1) DW3_LAUNCH(1); else if (mode == 2) DW3_LAUNCH(2); else DW3_LAUNCH(3);
+#undef DW3_LAUNCH
+  DGTD_CHECK_LAUNCH("dwconv3_sw");
+  return 0;
+}
+
 // 2 channels per lane (one 4-byte bf16x2 / 8-byte float2 load); one wave = 128 channels of one strip.
 template <typename T> struct Pair;
 template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -625,6 +725,12 @@ extern "C" int dgtd_dwconv_fwd(const void* x, const float* w_t, const float* bia
   // measured (profiles/r01_ops_device_times.txt): the LDS-tiled kernel wins 1.6-1.8x for 7x7 (49-tap halo reuse); for 3x3 the direct
   // kernel with 16-byte loads is as fast or faster
   if (K == 7 && C % 128 == 0 && use_tiled()) return dgtd_dwconv_tiled_fwd(x, w_t, bias, aux, y, B, H, W, C, K, mode, dt, st);
+  static const bool sw3 = !(getenv("DGTD_DWCONV3_SLIDING") && getenv("DGTD_DWCONV3_SLIDING")[0] == '0');
+  if (K == 3 && C % 4 == 0 && sw3 && H >= 8) {
+    if (dt == DGTD_BF16) return fwd3_sw_launch<bf16_t>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+    if (dt == DGTD_F16) return fwd3_sw_launch<f16_t>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+    return fwd3_sw_launch<float>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
+  }
   if (dt == DGTD_BF16) return K == 7 ? fwd_launch<bf16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
                                      : fwd_launch<bf16_t, 8, 3, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st);
   if (dt == DGTD_F16) return K == 7 ? fwd_launch<f16_t, 4, 7, 4>(x, w_t, bias, aux, y, B, H, W, C, mode, st)
