@@ -50,8 +50,11 @@ inline bool enabled() {
   return on;
 }
 
-inline bool tune() {   // DGTD_GEMM_TUNE=1: pick among the heuristic's candidates by measurement (measured: no gain on this model, off by default)
-  static const bool on = [] { const char* e = std::getenv("DGTD_GEMM_TUNE"); return e && e[0] == '1'; }();
+// Pick among the heuristic's first candidates by measurement when a plan is created (once per shape and thread).  With the step
+// replayed as a hipGraph (GPU-bound) this is worth 0.7 ms of 33.4 per step at config 2 (245 vs 240 images/s); in the host-bound eager
+// step of round 1 it showed nothing.  DGTD_GEMM_TUNE=0 takes the heuristic's first answer.
+inline bool tune() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_GEMM_TUNE"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -112,31 +115,34 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
       constexpr int kTry = 8;
       hipblasLtMatmulHeuristicResult_t res[kTry];
       int found = 0;
-      good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, tune() ? kTry : 1, res, &found)) && found > 0;
+      // a plan first needed while the stream is being captured cannot be timed (event synchronisation is illegal there): first answer
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool timing = tune() && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+      good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, timing ? kTry : 1, res, &found)) && found > 0;
       int best = -1;
       if (good && found > 1) {
         // one-time selection among the heuristic's candidates by measurement (the top-1 pick is not always the fastest for the
         // skinny token-major shapes of this model): 1 warm-up + 3 timed runs each, on the caller's stream
         const float alpha = 1.f, beta = 0.f;
         hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
         float best_ms = 1e30f;
         for (int i = 0; i < found; ++i) {
           if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kWorkspace) continue;
           bool run_ok = true;
           for (int r = 0; r < 4 && run_ok; ++r) {
-            if (r == 1) hipEventRecord(e0, st);
+            if (r == 1) (void)hipEventRecord(e0, st);
             run_ok = ok(hipblasLtMatmul(c.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, D, p.d, D, p.d, &res[i].algo, c.ws.data_ptr(),
                                         kWorkspace, st));
           }
-          hipEventRecord(e1, st);
-          hipEventSynchronize(e1);
+          (void)hipEventRecord(e1, st);
+          (void)hipEventSynchronize(e1);
           float ms = 0.f;
           if (run_ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = i; }
         }
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
       } else if (good && res[0].workspaceSize <= kWorkspace) {
         best = 0;
       }
