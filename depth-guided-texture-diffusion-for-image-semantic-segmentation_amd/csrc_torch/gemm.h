@@ -112,8 +112,9 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
       set_batch(p.d, batch, sD);
     }
     if (good) {
-      constexpr int kTry = 8;
-      hipblasLtMatmulHeuristicResult_t res[kTry];
+      constexpr int kMaxTry = 32;
+      static const int kTry = [] { const char* e = std::getenv("DGTD_GEMM_CANDIDATES"); const int v = e ? std::atoi(e) : 32; return v < 1 ? 1 : (v > kMaxTry ? kMaxTry : v); }();
+      hipblasLtMatmulHeuristicResult_t res[kMaxTry];
       int found = 0;
       // a plan first needed while the stream is being captured cannot be timed (event synchronisation is illegal there): first answer
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

@@ -4,6 +4,8 @@ import sys
 # before anything imports torch (MIOpen reads its environment when the library is loaded): fp32 Winograd convolutions off, see
 # <package>/__init__.py.  fp32 is the parity mode; the 16-bit modes do not reach MIOpen for 3x3 stride-1 convolutions.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+# library-GEMM plans time the heuristic's candidates once per shape; the tests see hundreds of shapes and need no speed record
+os.environ.setdefault("DGTD_GEMM_CANDIDATES", "4")
 
 import pytest
 
