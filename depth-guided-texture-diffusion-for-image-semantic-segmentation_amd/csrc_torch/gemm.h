@@ -7,6 +7,9 @@
 #include <ATen/ATen.h>
 #include <hip/hip_runtime_api.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+
+#include <vector>
 
 #include <cstdlib>
 #include <unordered_map>
@@ -55,6 +58,13 @@ inline bool enabled() {
 // step of round 1 it showed nothing.  DGTD_GEMM_TUNE=0 takes the heuristic's first answer.
 inline bool tune() {
   static const bool on = [] { const char* e = std::getenv("DGTD_GEMM_TUNE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// DGTD_GEMM_EXHAUSTIVE=1: time EVERY library solution that supports the problem instead of the heuristic's first candidates
+// (hipblaslt_ext::getAllAlgos; hundreds per plan, seconds per shape - an offline-tuning switch, off by default)
+inline bool exhaustive() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_GEMM_EXHAUSTIVE"); return e && e[0] == '1'; }();
   return on;
 }
 
@@ -120,6 +130,27 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       const bool timing = tune() && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
       good = ok(hipblasLtMatmulAlgoGetHeuristic(c.handle, p.desc, p.a, p.b, p.d, p.d, c.pref, timing ? kTry : 1, res, &found)) && found > 0;
+      std::vector<hipblasLtMatmulHeuristicResult_t> all;
+      if (good && timing && exhaustive()) {
+        const float one = 1.f, zero = 0.f;
+        std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+        if (ok(hipblaslt_ext::getAllAlgos(c.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, opA, opB, DT, DT, DT, DT, HIPBLAS_COMPUTE_32F, cand))) {
+          for (auto& r : cand) {
+            size_t need = 0;
+            if (ok(hipblaslt_ext::matmulIsAlgoSupported(c.handle, p.desc, &one, p.a, p.b, &zero, p.d, p.d, r.algo, need)) && need <= kWorkspace) {
+              r.workspaceSize = need;
+              r.state = HIPBLAS_STATUS_SUCCESS;
+              all.push_back(r);
+            }
+          }
+        }
+      }
+      hipblasLtMatmulHeuristicResult_t* list = res;
+      if (!all.empty()) {
+        for (int i = 0; i < found; ++i) all.push_back(res[i]);
+        list = all.data();
+        found = (int)all.size();
+      }
       int best = -1;
       if (good && found > 1) {
         // one-time selection among the heuristic's candidates by measurement (the top-1 pick is not always the fastest for the
@@ -130,11 +161,11 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
         (void)hipEventCreate(&e1);
         float best_ms = 1e30f;
         for (int i = 0; i < found; ++i) {
-          if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kWorkspace) continue;
+          if (list[i].state != HIPBLAS_STATUS_SUCCESS || list[i].workspaceSize > kWorkspace) continue;
           bool run_ok = true;
           for (int r = 0; r < 4 && run_ok; ++r) {
             if (r == 1) (void)hipEventRecord(e0, st);
-            run_ok = ok(hipblasLtMatmul(c.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, D, p.d, D, p.d, &res[i].algo, c.ws.data_ptr(),
+            run_ok = ok(hipblasLtMatmul(c.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, D, p.d, D, p.d, &list[i].algo, c.ws.data_ptr(),
                                         kWorkspace, st));
           }
           (void)hipEventRecord(e1, st);
@@ -144,11 +175,11 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-      } else if (good && res[0].workspaceSize <= kWorkspace) {
+      } else if (good && list[0].workspaceSize <= kWorkspace) {
         best = 0;
       }
       good = best >= 0;
-      if (good) p.algo = res[best].algo;
+      if (good) p.algo = list[best].algo;
     }
     p.ok = good;
     it = c.plans.emplace(key, p).first;

@@ -11,7 +11,7 @@ import sys
 
 
 def category(n: str) -> str:
-    if n.startswith("Cijk"):
+    if n.startswith("Cijk") or n.startswith("Custom_Cijk"):
         return "library GEMM (hipBLASLt)"
     if any(k in n for k in ("igemm", "naive_conv", "SubTensorOp", "batched_transpose", "Im2d", "Col2Im", "grouped_conv", "gridwise", "miopen")):
         return "library dense conv (MIOpen, incl. its layout transforms)"
