@@ -75,3 +75,23 @@ def test_fold_2x2_mean_matches_avg_pool_and_its_gradient():
         ga, = torch.autograd.grad(ya, a, g)
         gb, = torch.autograd.grad(yb, b, g)
         torch.testing.assert_close(ga, gb, rtol=1e-6, atol=1e-6)
+
+
+def test_block_run_is_a_no_op_without_the_native_layer():
+    """ops.block_run (arena hints for the deferred weight-gradient GEMMs) must not touch anything on CPU tensors / without the C++
+    binding layer: modules call it unconditionally."""
+    import torch
+    import dgtd
+    from dgtd import ops
+
+    class Owner(torch.nn.Module):
+        pass
+
+    owner, x = Owner(), torch.zeros(2, 4)
+    with ops.block_run(owner, 0, 3, x) as run:
+        for j in range(3):
+            run.at(j)
+            run.roles(out=0, grad_a=1, grad_b=2)
+    assert "_dgtd_arena_token" not in owner.__dict__
+    ops.NO_RUN.at(0)
+    ops.NO_RUN.roles(out=1)
