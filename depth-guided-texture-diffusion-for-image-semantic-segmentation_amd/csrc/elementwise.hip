@@ -203,30 +203,46 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ g, c
   for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; gm[j] = (MODE == 3 && gamma) ? gamma[cv * V + j] : 1.f; }
   const bool need_y = MODE == 4 || gamma != nullptr;
   if (rg < RG) {
-    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < rows; r += (int64_t)gridDim.x * RG) {
-      const size_t off = (size_t)r * C + (size_t)cv * V;
-      const VT gv = *reinterpret_cast<const VT*>(g + off);
-      VT yv = gv, o;
-      if (need_y) yv = *reinterpret_cast<const VT*>(y + off);
-      if (MODE == 3) {
-        const float sb = s ? s[r / rows_per_sample] : 1.f;
+    // U rows in flight per thread (loads of all U rows issued before the first is consumed): one row per iteration leaves two
+    // 16-byte loads outstanding per lane, far too little for HBM
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * RG;
+    for (int64_t r0 = (int64_t)blockIdx.x * RG + rg; r0 < rows; r0 += stride * U) {
+      VT gv[U], yv[U];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float gg = sb * (float)gv[j];
-          accA[j] += gg * (float)yv[j];
-          const float d = gg * gm[j];
-          accB[j] += d;
-          o[j] = (T)d;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float d = (float)gv[j] * gelu_grad_fast((float)yv[j]);
-          accB[j] += d;
-          o[j] = (T)d;
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * stride;
+        if (r < rows) {
+          const size_t off = (size_t)r * C + (size_t)cv * V;
+          gv[u] = *reinterpret_cast<const VT*>(g + off);
+          yv[u] = need_y ? *reinterpret_cast<const VT*>(y + off) : gv[u];
         }
       }
-      *reinterpret_cast<VT*>(dy + off) = o;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * stride;
+        if (r >= rows) break;
+        VT o;
+        if (MODE == 3) {
+          const float sb = s ? s[r / rows_per_sample] : 1.f;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float gg = sb * (float)gv[u][j];
+            accA[j] += gg * (float)yv[u][j];
+            const float d = gg * gm[j];
+            accB[j] += d;
+            o[j] = (T)d;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float d = (float)gv[u][j] * gelu_grad_fast((float)yv[u][j]);
+            accB[j] += d;
+            o[j] = (T)d;
+          }
+        }
+        *reinterpret_cast<VT*>(dy + (size_t)r * C + (size_t)cv * V) = o;
+      }
     }
   }
   float* wrow = ws + (size_t)blockIdx.x * 2 * C + (size_t)blockIdx.y * 256 * V;
