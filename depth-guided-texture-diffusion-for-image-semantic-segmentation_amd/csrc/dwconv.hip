@@ -4,11 +4,16 @@
 // both of which the reference runs in NCHW behind two permute copies.
 //
 // HBM-bound.  Algorithmic bytes: fwd 2*e*B*H*W*C;  bwd-data 2*e*B*H*W*C;  bwd-weight 2*e*B*H*W*C (+K*K*C*4).
-// Mapping: channels are the contiguous dim, so lanes run along C (16 B per lane in fwd -> fully coalesced rows);
-// each thread produces a strip of TX consecutive x positions so the K taps along x are reused from registers;
-// the K-fold reuse along y is served by L1/L2 (neighbouring rows are computed by neighbouring workgroups).
-// bwd-data is the same kernel with the spatially flipped filter.  bwd-weight keeps a K*K x 2-channel accumulator per
-// lane, sums the four waves of a workgroup through LDS atomics and leaves with one fp32 global atomic per tap/channel.
+// Mapping: channels are the contiguous dim, so lanes run along C (coalesced rows).
+//   7x7 forward / input gradient: LDS-tiled kernels (dwconv_tiled.hip); direct strip kernel kept for C % 128 != 0.
+//   3x3 forward / input gradient: sliding window (dwconv3_sw_kernel) - a thread owns 4 x-positions x 4 channels and walks down the
+//     image with the three input rows in registers, every row loaded once; modes fuse bias, GELU, GELU' and the skip-gradient add.
+//   weight gradient, one layer per launch: K waves per workgroup = the K filter rows of a strip column, per-workgroup partial rows,
+//     fixed-order second stage (no atomics anywhere).
+//   weight gradient, all same-shaped layers of the step in one launch (deferred phase): dwconv_bww_sw_kernel - one wave
+//     owns all K filter rows of a strip and slides down the image, gradient rows in a register window.
+//   weights are packed to fp32 tap-major (+ spatially flipped copy + bias) once per step for all layers (dwconv_pack_batched).
+// bwd-data is the forward kernel with the spatially flipped filter.
 #include "common.h"
 #include <stdlib.h>
 
