@@ -135,6 +135,57 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(const T* __restrict__ res
   }
 }
 
+// The per-sample MLP folded into the apply pass: grid (slices, B); every workgroup recomputes gate[b][:] from the pooled partial sums
+// (C + R*C + C*R MACs, the same arithmetic in the same order as ca_gate_mlp_kernel, so all workgroups of a sample agree bit for bit)
+// and applies it to its slice of the sample; workgroup 0 of the sample also writes pooled / hidden / gate for the backward.  The
+// stand-alone MLP launch was 8.6 us of pure latency (one small workgroup per sample, three dependent phases) in front of a 5 us pass.
+template <typename T>
+__global__ __launch_bounds__(256) void ca_apply_fused_kernel(const T* __restrict__ res, const T* __restrict__ x, const float* __restrict__ partial,
+                                                             int nparts, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                             float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ gate,
+                                                             T* __restrict__ out, int HW, int C, int R) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  __shared__ float m[128], hdn[32], gt[128];
+  const int b = blockIdx.y, B = gridDim.y, tid = threadIdx.x;
+  const bool keeper = blockIdx.x == 0;
+  if (tid < C) {
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nparts; k += 2) { s0 += partial[((size_t)k * B + b) * C + tid]; s1 += partial[((size_t)(k + 1) * B + b) * C + tid]; }
+    if (k < nparts) s0 += partial[((size_t)k * B + b) * C + tid];
+    const float sum = s0 + s1;
+    if (keeper) pooled[b * C + tid] = sum;
+    m[tid] = sum / (float)HW;
+  }
+  __syncthreads();
+  if (tid < R) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += w1[tid * C + c] * m[c];
+    a = fmaxf(a, 0.f);
+    hdn[tid] = a;
+    if (keeper) hidden[b * R + tid] = a;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a += w2[tid * R + j] * hdn[j];
+    const float gv = 1.f / (1.f + expf(-a));
+    gt[tid] = gv;
+    if (keeper) gate[b * C + tid] = gv;
+  }
+  __syncthreads();
+  const int CV = C / V;
+  const size_t base = (size_t)b * HW * CV;
+  for (int i = blockIdx.x * 256 + tid; i < HW * CV; i += gridDim.x * 256) {
+    const int cv = i % CV;
+    VT r = *reinterpret_cast<const VT*>(res + (base + i) * V), xv = *reinterpret_cast<const VT*>(x + (base + i) * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = (T)((float)r[j] * gt[cv * V + j] + (float)xv[j]);
+    *reinterpret_cast<VT*>(out + (base + i) * V) = o;
+  }
+}
+
 // backward of the tiny MLP, one workgroup per sample: dgate_sum[b][c] = sum_hw g*res (per-slice partials, summed here in a fixed
 // order) -> dmean[b][c]; the per-sample outer products dz x hidden and dh x mean go to dwp[b][2*R*C] and are summed over the batch
 // in a fixed order by workgroup 0 of ca_apply_bwd_kernel (deterministic, nothing to zero, no extra launch)
@@ -196,6 +247,84 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < V; ++j) o[j] = (T)((float)gv[j] * gate[b * C + cv * V + j] + dmean[b * C + cv * V + j]);
     *reinterpret_cast<VT*>(dres + i * V) = o;
+  }
+}
+
+// The MLP backward folded into the apply pass (grid (slices, B), B <= CA_MAXB): every workgroup derives dz / dh / dmean of ITS sample
+// (same arithmetic and order as ca_gate_mlp_bwd_kernel); workgroup (0, 0) additionally derives them for ALL samples at once and sums
+// the per-sample outer products over the batch in a fixed order -> dw1, dw2 (the stand-alone kernel cost 11.4 us of latency).
+constexpr int CA_MAXB = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void ca_apply_bwd_fused_kernel(const T* __restrict__ g, const float* __restrict__ partial, int nparts,
+                                                                 const float* __restrict__ gate, const float* __restrict__ hidden,
+                                                                 const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                                 const float* __restrict__ w2, T* __restrict__ dres, float* __restrict__ dw1,
+                                                                 float* __restrict__ dw2, int HW, int C, int R) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ float sh[];                 // own sample: dz[128] dh[32] gt[128] dm[128]; workgroup (0,0): + all samples dzA[B*128] dhA[B*32]
+  float *dz = sh, *dh = sh + 128, *gt = sh + 160, *dm = sh + 288, *dzA = sh + 416, *dhA = dzA + (size_t)gridDim.y * 128;
+  const int b = blockIdx.y, B = gridDim.y, tid = threadIdx.x;
+  auto dgate_sum = [&](int bb, int c) {
+    float d0 = 0.f, d1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nparts; k += 2) { d0 += partial[((size_t)k * B + bb) * C + c]; d1 += partial[((size_t)(k + 1) * B + bb) * C + c]; }
+    if (k < nparts) d0 += partial[((size_t)k * B + bb) * C + c];
+    return d0 + d1;
+  };
+  if (tid < C) {
+    const float gv = gate[b * C + tid];
+    gt[tid] = gv;
+    dz[tid] = dgate_sum(b, tid) * gv * (1.f - gv);           // through the sigmoid
+  }
+  __syncthreads();
+  if (tid < R) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += w2[c * R + tid] * dz[c];
+    dh[tid] = hidden[b * R + tid] > 0.f ? a : 0.f;           // through the ReLU
+  }
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a += w1[j * C + tid] * dh[j];
+    dm[tid] = a / (float)HW;                                  // d loss / d res[b][hw][c] through the mean
+  }
+  if (blockIdx.x == 0 && b == 0) {                            // weight gradients: all samples, summed over the batch in sample order
+    for (int i = tid; i < B * C; i += 256) {
+      const int bb = i / C, c = i % C;
+      const float gv = gate[bb * C + c];
+      dzA[bb * 128 + c] = dgate_sum(bb, c) * gv * (1.f - gv);
+    }
+    __syncthreads();
+    for (int i = tid; i < B * R; i += 256) {
+      const int bb = i / R, j = i % R;
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += w2[c * R + j] * dzA[bb * 128 + c];
+      dhA[bb * 32 + j] = hidden[bb * R + j] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * R * C; i += 256) {
+      float a = 0.f;
+      if (i < R * C) {                                        // dw1[j][c] = sum_b dh_b[j] * mean_b[c]
+        const int j = i / C, c = i % C;
+        for (int bb = 0; bb < B; ++bb) a += dhA[bb * 32 + j] * (pooled[bb * C + c] / (float)HW);
+        dw1[i] = a;
+      } else {                                                // dw2[c][j] = sum_b dz_b[c] * hidden_b[j]
+        const int k = i - R * C, c = k / R, j = k % R;
+        for (int bb = 0; bb < B; ++bb) a += dzA[bb * 128 + c] * hidden[bb * R + j];
+        dw2[k] = a;
+      }
+    }
+  }
+  __syncthreads();
+  const int CV = C / V;
+  const size_t base = (size_t)b * HW * CV;
+  for (int i = blockIdx.x * 256 + tid; i < HW * CV; i += gridDim.x * 256) {
+    const int cv = i % CV;
+    VT gv = *reinterpret_cast<const VT*>(g + (base + i) * V), o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = (T)((float)gv[j] * gt[cv * V + j] + dm[cv * V + j]);
+    *reinterpret_cast<VT*>(dres + (base + i) * V) = o;
   }
 }
 
@@ -342,6 +471,15 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
   else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, false>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)nullptr, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, false>), dim3(gx, B), dim3(256), 0, st, (const float*)res, (const float*)nullptr, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_pooled_sum");
+  static const bool fused = !(getenv("DGTD_CA_FUSED") && getenv("DGTD_CA_FUSED")[0] == '0');
+  if (fused && B <= 65535) {
+    const int ax = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)HW * (C / V), 256 * 2), 128));
+    if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_fused_kernel<f16_t>, dim3(ax, B), dim3(256), 0, st, (const f16_t*)res, (const f16_t*)x, (const float*)partial, gx, w1, w2, pooled, hidden, gate, (f16_t*)out, HW, C, R);
+    else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_fused_kernel<bf16_t>, dim3(ax, B), dim3(256), 0, st, (const bf16_t*)res, (const bf16_t*)x, (const float*)partial, gx, w1, w2, pooled, hidden, gate, (bf16_t*)out, HW, C, R);
+    else hipLaunchKernelGGL(ca_apply_fused_kernel<float>, dim3(ax, B), dim3(256), 0, st, (const float*)res, (const float*)x, (const float*)partial, gx, w1, w2, pooled, hidden, gate, (float*)out, HW, C, R);
+    DGTD_CHECK_LAUNCH("ca_apply_fused");
+    return 0;
+  }
   hipLaunchKernelGGL(ca_gate_mlp_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, pooled, w1, w2, gate, hidden, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp");
   const int64_t rows = (int64_t)B * HW;
@@ -367,6 +505,16 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   else if (dt == DGTD_BF16) hipLaunchKernelGGL((pooled_sum_kernel<bf16_t, true>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)res, partial, HW, C);
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
+  static const bool fused = !(getenv("DGTD_CA_FUSED") && getenv("DGTD_CA_FUSED")[0] == '0');
+  if (fused && B <= CA_MAXB) {
+    const int ax = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)HW * (C / V), 256 * 2), 128));
+    const size_t lds = (size_t)(416 + B * 160) * sizeof(float);
+    if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<f16_t>, dim3(ax, B), dim3(256), lds, st, (const f16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (f16_t*)dres, dw1, dw2, HW, C, R);
+    else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<bf16_t>, dim3(ax, B), dim3(256), lds, st, (const bf16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (bf16_t*)dres, dw1, dw2, HW, C, R);
+    else hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<float>, dim3(ax, B), dim3(256), lds, st, (const float*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (float*)dres, dw1, dw2, HW, C, R);
+    DGTD_CHECK_LAUNCH("ca_apply_bwd_fused");
+    return 0;
+  }
   hipLaunchKernelGGL(ca_gate_mlp_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)partial, gx, gate, hidden, pooled, w1, w2, dmean, dwp, HW, C, R);
   DGTD_CHECK_LAUNCH("ca_gate_mlp_bwd");
   const int64_t rows = (int64_t)B * HW;
