@@ -467,8 +467,11 @@ inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
   const int tw = W >= 32 ? 32 : 16, th = Ci >= 64 ? 4 : 8;
   const long ntiles = (long)B * cdiv(H, th) * cdiv(W, tw);
   const long ygroups = (long)Z * cdiv(Co, 32) * (Ci > 32 ? 3 : 1);
-  static const long wgs = getenv("DGTD_WGRAD_WGS") ? atol(getenv("DGTD_WGRAD_WGS")) : 512;
-  const long want = std::max<long>(1, wgs / ygroups);                              // ~2 workgroups per CU
+  // ~2 workgroups per CU; 96 -> 96 channels (9 output tiles x 3 filter-row groups per pixel split) runs better with ~4 (measured:
+  // 16 convolutions at 64x64 343 -> 304 us; every other geometry of the model is slower with more partial sums)
+  static const long wgs_env = getenv("DGTD_WGRAD_WGS") ? atol(getenv("DGTD_WGRAD_WGS")) : 0;
+  const long wgs = wgs_env ? wgs_env : (Ci >= 96 && Co >= 96 ? 1024 : 512);
+  const long want = std::max<long>(1, wgs / ygroups);
   // the partial sums written (and re-read by the reduce kernel) should stay below the bytes of the two input maps
   const long in_bytes = 2L * ((long)Z * B * H * W * (Ci + Co)), part_bytes = (long)Z * cdiv(Co, 32) * 32 * 9 * ((Ci + 31) / 32 * 32) * 4;
   const long cap = std::max<long>(std::max<long>(4, in_bytes / part_bytes), (16L << 20) / part_bytes);   // small maps: up to 16 MB of partials
