@@ -180,20 +180,41 @@ def main():
         return prob.mean()
 
     step = train_step if train else predict_step
-    graphed = None
+    graphed, graph_mode = None, None
     if want_graph:
-        try:
-            graphed = dgtd.runner.GraphedTrainStep(net, reducer, opt, scaler=scaler, warmup=2)
-            tg = time.perf_counter()
-            graphed.capture(batches[0])
-            step = lambda i: graphed(batches[i % len(batches)])
-            print(f"[bench] hipGraph capture of the training step: ok ({time.perf_counter() - tg:.1f} s)", file=sys.stderr, flush=True)
-        except Exception as e:  # the eager step stays available; say so in the result line
+        # N > 1: first the ONE-graph form with the RCCL all-reduces captured on the side stream (overlapped with backward), then the
+        # split form (graph A | eager all-reduce | graph B), then the eager step with hook-driven overlap.  Every rank must take the
+        # same path (the collectives differ), so the outcome of each attempt is agreed on with a MIN all-reduce.
+        multi = world > 1 or reducer._force
+        tried = set()
+        for comm in ((os.environ.get("DGTD_GRAPH_COMM", "auto"), "split") if multi else ("auto",)):
+            cand, ok, err = None, 1, None
+            try:
+                cand = dgtd.runner.GraphedTrainStep(net, reducer, opt, scaler=scaler, warmup=2, comm=comm)
+                if cand.mode in tried:          # "auto" already resolved to this mode and failed
+                    continue
+                tried.add(cand.mode)
+                tg = time.perf_counter()
+                cand.capture(batches[0])
+            except Exception as e:  # the eager step stays available; say so in the result line
+                ok, err = 0, e
+            if world > 1:
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                if ok and not int(flag.item()):
+                    ok, err = 0, RuntimeError("capture failed on another rank")
+            if ok:
+                graphed, graph_mode = cand, cand.mode
+                step = lambda i: graphed(batches[i % len(batches)])
+                print(f"[bench] hipGraph capture of the training step ({cand.mode}): ok ({time.perf_counter() - tg:.1f} s)", file=sys.stderr, flush=True)
+                break
+            if cand is not None:
+                cand.release()
+            print(f"[bench] hipGraph capture ({comm}) failed ({type(err).__name__}: {err})", file=sys.stderr, flush=True)
+        if graphed is None:
             if args.graph == "on":
-                raise
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
-            reducer.overlap = getattr(graphed, "_overlap_before", reducer.overlap)
-            graphed = None
+                raise RuntimeError("hipGraph capture failed and --graph on was given")
+            print("[bench] running the eager step", file=sys.stderr, flush=True)
             step = train_step
 
     def barrier():
@@ -227,8 +248,10 @@ def main():
     final_loss = loss.item()
 
     # ---- instrumented pass: per-call HIP-event timing inside libdgtd.so (not part of `value`)
-    roofline, kernels, attention = None, [], []
-    if rank == 0 and args.profile_steps > 0:
+    roofline, kernels, attention, entries = None, [], [], []
+    if args.profile_steps > 0:
+        # EVERY rank runs the instrumented steps (they are eager training steps: with N > 1 each issues the bucketed all-reduces, which
+        # must meet their peers - rank 0 alone would hang against the others' barrier); rank 0 summarises.
         # The timing lives in the C ABI (dgtd_profile_enable), so this pass runs EXACTLY the autograd nodes of the timed step (the
         # C++ bindings and their fused nodes included).  The step is partly host-bound, so an event pair around a launch would also
         # time the host's enqueue gap: each instrumented step is queued BEHIND a ballast of large GEMMs (about 2.5 step-times of
@@ -249,25 +272,42 @@ def main():
         for i in range(args.profile_steps):
             for _ in range(n_ball):
                 torch.mm(ball, ball, out=ball_out)
+            for _ in range(16):                                # empty brackets behind the same ballast: the event pair's own floor
+                dgtd._lib.call("dgtd_profile_empty", dgtd._lib.stream_ptr())
             prof_step(i)
         del ball, ball_out
         summ = dgtd._lib.profile_native_summary()
         dgtd._lib.profile_native(False)
         log("instrumented pass done")
+    if rank == 0 and args.profile_steps > 0:
         mfma_peak = {torch.bfloat16: "mfma_bf16", torch.float16: "mfma_f16", torch.float32: "mfma_f32"}[dtype]
+        empty = summ.pop("dgtd_profile_empty", None)
+        floor_ms = (empty["ms"] / empty["calls"]) if empty and empty["calls"] else 0.0      # per-call floor of the event bracket itself
+        clock = (f"HIP event pair inside libdgtd.so around the entry's launches, minus the empty-bracket floor measured in the same pass "
+                 f"({1e3 * floor_ms:.2f} us per call)")
+
+        def record(key, calls, ms, amount, mfma):
+            ms = max(ms - floor_ms * calls, 1e-6)
+            peak, unit = PEAK[mfma_peak if mfma else "hbm"]
+            per_s = amount / (ms * 1e-3)
+            achieved = per_s / 1e12 if mfma else per_s / 1e9
+            rec = {"kernel": key, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
+                   "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": calls / args.profile_steps,
+                   "avg_us": round(1e3 * ms / calls, 2), "ms_per_step": round(ms / args.profile_steps, 3), "traffic": None}
+            rec["algorithmic_flops" if mfma else "algorithmic_bytes"] = round(amount / calls)
+            return rec
+
+        by_entry = {}
         for key, e in summ.items():
             if e["amount"] <= 0 or e["ms"] <= 0:
                 continue
             mfma = e["bound"] == "mfma"
-            peak, unit = PEAK[mfma_peak if mfma else "hbm"]
-            per_s = e["amount"] / (e["ms"] * 1e-3)
-            achieved = per_s / 1e12 if mfma else per_s / 1e9
-            rec = {"kernel": key, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
-                   "unit": unit, "frac": round(achieved / peak, 4), "calls_per_step": e["calls"] / args.profile_steps,
-                   "avg_us": round(1e3 * e["ms"] / e["calls"], 2), "ms_per_step": round(e["ms"] / args.profile_steps, 3),
-                   "traffic": None}
-            rec["algorithmic_flops" if mfma else "algorithmic_bytes"] = round(e["amount"] / e["calls"])
-            kernels.append(rec)
+            kernels.append(record(key, e["calls"], e["ms"], e["amount"], mfma))
+            g = by_entry.setdefault((key.split("[")[0], mfma), {"calls": 0, "ms": 0.0, "amount": 0.0, "shapes": 0})
+            g["calls"] += e["calls"]
+            g["ms"] += e["ms"]
+            g["amount"] += e["amount"]
+            g["shapes"] += 1
         # HBM bytes per launch measured OFFLINE with rocprofv3 PMC passes of the same kernels at the same shapes (tools/pmc_run.sh:
         # FETCH_SIZE x2 + WRITE_SIZE in separate runs, MI355X_MICROARCH.md), read from the committed profiles/; null where no pass exists
         pmc = {}
@@ -279,19 +319,37 @@ def main():
         for k in kernels:
             k["traffic"] = pmc.get(k["kernel"])
         kernels.sort(key=lambda k: -k["ms_per_step"])
+        # per C-ABI ENTRY over all its shapes (amount-weighted: total algorithmic bytes or flops / total device time): the entry with
+        # the most time per step is the step's dominant hand-written kernel and carries the bench line's `roofline`
+        for (name, mfma), g in by_entry.items():
+            r = record(name, g["calls"], g["ms"], g["amount"], mfma)
+            r["shapes"] = g["shapes"]
+            entries.append(r)
+        entries.sort(key=lambda k: -k["ms_per_step"])
         # MFMA utilisation of the attention GEMMs (QK^T and AV, and their gradients), every stage: flops / device time / dense peak
-        attention = [k for k in kernels if k["bound"] == "mfma"]
+        attention = [k for k in kernels if k["kernel"].startswith("dgtd_sra_attn")]
         if args.all_kernels:
             with open(args.all_kernels, "w") as f:
-                json.dump(kernels, f, indent=0)
-        if kernels:
-            roofline = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-            roofline["traffic_source"] = "offline rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE), HBM bytes per launch"
+                json.dump({"entries": entries, "kernels": kernels, "clock": clock}, f, indent=0)
+        if entries:
+            top = entries[0]
+            roofline = {k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+            # traffic: PMC bytes of the entry's shapes that have a pass, scaled to the entry's average launch
+            shapes = [k for k in kernels if k["kernel"].split("[")[0] == top["kernel"] and k["traffic"]]
+            if shapes and not top["bound"] == "mfma":
+                cov_alg = sum(k["algorithmic_bytes"] * k["calls_per_step"] for k in shapes)
+                cov_pmc = sum(k["traffic"] * k["calls_per_step"] for k in shapes)
+                roofline["traffic"] = round(top["algorithmic_bytes"] * cov_pmc / cov_alg)
+                roofline["traffic_source"] = (f"offline rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE) for {len(shapes)} of the "
+                                              f"entry's {top['shapes']} shapes: measured / algorithmic = {cov_pmc / cov_alg:.3f}, applied to the average launch")
+            else:
+                roofline["traffic"] = None
             for extra in ("algorithmic_bytes", "algorithmic_flops"):
-                if extra in kernels[0]:
-                    roofline[extra] = kernels[0][extra]
-            roofline["kernel"] = kernels[0]["kernel"]
-            roofline["avg_us"] = kernels[0]["avg_us"]
+                if extra in top:
+                    roofline[extra] = top[extra]
+            roofline.update(kernel=top["kernel"], avg_us=top["avg_us"], ms_per_step=top["ms_per_step"], calls_per_step=top["calls_per_step"],
+                            shapes=top["shapes"], clock=clock,
+                            what="the C-ABI entry with the most device time per step, all its shapes pooled (amount-weighted)")
     if world > 1:
         torch.distributed.barrier()
 
@@ -310,12 +368,13 @@ def main():
                                    f"{args.size}x{args.size} RGB+depth, batch {args.batch}/GPU, random init, "
                                    + ("DropPath active" if train else "eval mode, no_grad"),
                        "mode": args.mode, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hip_graph": graphed is not None,
+                       "hip_graph": graphed is not None, "graph_mode": graph_mode,
+                       "allreduce_payload": (None if not (world > 1 or reducer._force) else ("16-bit working dtype + fp32 rest" if reducer.comm16 else "fp32")),
                        "final_loss": round(final_loss, 4) if train else None,
                        "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2),
                        "reference_algorithmic_tflops": round(imgs / dt * flops_per_img / 1e12, 2),
                        "loss_scale": scaler.get_scale() if scaler is not None else None},
-            "roofline": roofline, "kernels": kernels[:12], "attention_mfma": attention,
+            "roofline": roofline, "entries": entries[:10], "kernels": kernels[:12], "attention_mfma": attention,
         }
         if world == 1 and not args.no_miou:
             log("mIoU parity (HIP vs CPU oracle, 256 synthetic samples) ...")

@@ -22,6 +22,7 @@ SIGNATURES = {
     "dgtd_last_error": (C.c_char_p, []),
     "dgtd_profile_enable": (_i, [_i]),
     "dgtd_profile_dump": (_i64, [C.c_char_p, _i64]),
+    "dgtd_profile_empty": (_i, [_vp]),
     "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
     "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
     "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),

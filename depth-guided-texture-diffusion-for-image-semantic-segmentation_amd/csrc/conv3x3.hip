@@ -484,7 +484,12 @@ extern "C" int dgtd_conv3x3_supported(int Ci, int Co, int H, int W) { return sup
 
 extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
                                 int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s) {
-  DGTD_PROF(s, DGTD_HBM, 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co), "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
+  // roofline label: 18 Ci Co flop per pixel over 2 (Ci + Co) bytes; above the ridge (2.5 PF / 8 TB/s = 312 flop/B; 96 -> 96: 432) the
+  // call is priced against the MFMA peak, below it against HBM
+  const double conv_bytes = 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co);
+  const double conv_flops = 18.0 * Z * B * H * W * (double)Ci * Co;
+  const bool conv_mfma = conv_flops > 312.5 * conv_bytes;
+  DGTD_PROF(s, conv_mfma ? DGTD_MFMA : DGTD_HBM, conv_mfma ? conv_flops : conv_bytes, "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad sizes");
   DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_fwd: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);

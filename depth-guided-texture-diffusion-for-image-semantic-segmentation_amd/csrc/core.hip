@@ -57,6 +57,14 @@ extern "C" int dgtd_profile_enable(int on) {
   return 0;
 }
 
+// An EMPTY bracket: the event pair with nothing between its two records.  What it measures (the record-to-record latency of two
+// back-to-back events on a busy stream) is the floor every profiled call carries on top of its kernels' own duration; bench.py
+// subtracts the average of a few of these from every per-call figure and says so.
+extern "C" int dgtd_profile_empty(dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, 0.0, "dgtd_profile_empty");
+  return 0;
+}
+
 // one line per recorded call: "key\tbound\tamount\tmilliseconds\n" (bound: hbm | mfma).  Returns the number of bytes the full dump
 // needs (call with buf = NULL / cap = 0 to size it); waits for the recorded events; the records stay until the next enable(1).
 extern "C" int64_t dgtd_profile_dump(char* buf, int64_t cap) {

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <map>
+#include <set>
 #include <tuple>
 #include <mutex>
 #include <vector>
@@ -48,12 +49,40 @@ inline at::ScalarType st_of(const c10::IValue& v) { return (at::ScalarType)v.toI
 // shared between call sites (autograd adds their gradients on the fly) never take this path (only LayerNorm, Linear bias and gamma
 // gradients of the two trunks do; their parameters are used once per step).  Destinations are remembered as raw pointers: holding the
 // tensors would stop AccumulateGrad from stealing them (it would clone the unwritten memory instead).
+//
+// SOUNDNESS RULE: an unwritten tensor may be handed to autograd only if autograd will STEAL it as the leaf's .grad and no
+// other gradient of that leaf arrives before the flush.  Every node that defers a parameter gradient therefore asks may_defer(leaf)
+// in its backward: the leaf must be a true leaf seen by exactly ONE deferring forward call in this window (a bias shared by two call
+// sites, a module called twice: immediate path for all its calls, autograd's accumulation adds then only see written tensors), and
+// its .grad must still be undefined - if an earlier backward of the window already handed one over (gradient accumulation, two
+// backward() calls, retain_graph), the pending work is flushed first, so AccumulateGrad's `grad += new` reads written memory, and the
+// call takes the immediate path.
 struct PendingReduce { dgtd_reduce_entry e; Tensor ws; };
 static std::mutex g_pending_mu;
+static std::map<const void*, int> g_uses;                 // leaf data pointer -> deferring forward calls in this window
 static std::vector<PendingReduce> g_pending;
 static std::atomic<bool> g_defer{false};
 
 inline bool deferring() { return g_defer.load(std::memory_order_relaxed); }
+void flush_deferred();
+inline bool is_leaf(const Tensor& t) { return t.defined() && t.requires_grad() && !t.grad_fn(); }
+// forward side: remember the leaf (kept in the node, so its .grad can be inspected in the backward) and count the call
+inline void note_leaf(AutogradContext* ctx, const char* key, const Tensor& t) {
+  if (!deferring() || !is_leaf(t)) return;
+  ctx->saved_data[key] = t;
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  ++g_uses[t.data_ptr()];
+}
+inline bool may_defer(AutogradContext* ctx, const char* key) {
+  if (!deferring()) return false;
+  auto it = ctx->saved_data.find(key);
+  if (it == ctx->saved_data.end() || !it->second.isTensor()) return false;
+  const Tensor& leaf = it->second.toTensor();
+  if (leaf.grad().defined()) { flush_deferred(); return false; }
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  auto u = g_uses.find(leaf.data_ptr());
+  return u != g_uses.end() && u->second == 1;
+}
 inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, void* outB, dgtd_dtype dtB, int tr_rows = 0, int tr_cols = 0,
                  void* outC = nullptr) {
   std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -94,6 +123,13 @@ inline std::pair<int, int> take_grad_roles() {
   return r;
 }
 static std::map<std::pair<int64_t, int>, Tensor> g_arenas;
+// slots handed out in this window: a slot requested twice before the flush (two forwards of a module before one backward, a second
+// backward through a retained graph) would overwrite what autograd saved from the first request - the second request gets a plain
+// allocation instead (and, not being in an arena, takes the per-layer weight-gradient path)
+static std::set<std::tuple<int64_t, int, int>> g_slot_used;
+// a captured hipGraph holds raw arena addresses: while pinned, re-allocating an arena is an error (runner/graph.py)
+static std::atomic<bool> g_arena_pinned{false};
+void arena_pin(bool on) { g_arena_pinned.store(on); }
 
 void arena_hint(int64_t group, int64_t idx, int64_t count) { t_hint = Hint{count > 1 ? group : -1, (int)idx, (int)count}; t_roles = Roles{}; }
 void arena_release(int64_t group) {
@@ -111,9 +147,13 @@ inline Tensor arena_slot(const Hint& h, int role, at::IntArrayRef shape, const a
   std::vector<int64_t> full{h.count};
   full.insert(full.end(), shape.begin(), shape.end());
   std::lock_guard<std::mutex> lk(g_pending_mu);
+  if (!g_slot_used.insert({h.group, role, h.idx}).second) return at::empty(shape, opt);
   Tensor& a = g_arenas[{h.group, role}];
-  if (!a.defined() || a.sizes() != at::IntArrayRef(full) || a.scalar_type() != c10::typeMetaToScalarType(opt.dtype()) || a.device() != opt.device())
+  if (!a.defined() || a.sizes() != at::IntArrayRef(full) || a.scalar_type() != c10::typeMetaToScalarType(opt.dtype()) || a.device() != opt.device()) {
+    TORCH_CHECK(!g_arena_pinned.load(), "dgtd: a captured hipGraph references the per-stage arenas; a grad-enabled step with another shape would "
+                "re-allocate them under it (GraphedTrainStep.release() first)");
     a = at::empty(full, opt);
+  }
   // NOT a view: views share the arena's version counter, and every write into another slot would invalidate the tensors autograd
   // saved from this one.  A blob over the slot's memory with its own storage object (the deleter keeps the arena alive).
   Tensor keep = a;
@@ -229,6 +269,19 @@ inline bool conv_register(const Tensor& w_arg, const Tensor& w, const ConvKey& k
   if (it == g_conv_seen.end()) g_conv_seen.emplace(w.data_ptr(), ConvSeen{k, !leaf});
   else if (!(it->second.k == k) || !leaf) it->second.mixed = true;
   return leaf;
+}
+// has an earlier backward of this window already handed autograd a gradient for the leaf kept under `key`?  (then: flush, so that it
+// is written, and take the immediate path - the SOUNDNESS RULE above)
+inline bool leaf_has_grad(AutogradContext* ctx, const char* key) {
+  auto it = ctx->saved_data.find(key);
+  if (it == ctx->saved_data.end() || !it->second.isTensor()) return true;      // unknown leaf: never defer
+  if (!it->second.toTensor().grad().defined()) return false;
+  flush_deferred();
+  return true;
+}
+inline bool conv_dest_exists(const Tensor& w) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  return g_conv_dest.count(w.data_ptr()) > 0;
 }
 // backward: park this call; dw / db are set only for the first parked call of the weight.  false: take the immediate path.
 inline bool conv_park(const Tensor& x, const Tensor& dy, const Tensor& mask, const Tensor& w, const ConvKey& k, bool has_b, Tensor& dw, Tensor& db) {
@@ -415,6 +468,8 @@ void set_deferred(bool on) {
     g_conv_seen.clear();
     g_prelu_acc.clear();
     g_conv_flip.clear();
+    g_uses.clear();
+    g_slot_used.clear();
   } else {
     flush_deferred();
   }
@@ -439,6 +494,8 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
     ctx->save_for_backward({x, w32, stats});
+    note_leaf(ctx, "leaf_w", w);
+    note_leaf(ctx, "leaf_b", b);
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -450,7 +507,7 @@ struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
     Tensor dx = at::empty_like(x);
     Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
     Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C) / 4}, x.options().dtype(at::kFloat));
-    if (deferring()) {
+    if (may_defer(ctx, "leaf_w") && may_defer(ctx, "leaf_b")) {
       int nb = 0;
       check(dgtd_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
                                        nullptr, dx.data_ptr(), ws.data_ptr(), rows, (int)C, code(x), &nb, stream()), "dgtd_layernorm_bwd_partial");
@@ -479,6 +536,8 @@ struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
     check(dgtd_layernorm_fwd(x.data_ptr(), w32.data_ptr<float>(), b32.data_ptr<float>(), y.data_ptr(), stats.data_ptr<float>(),
                              stats.data_ptr<float>() + rows, rows, (int)C, (float)eps, code(x), stream()), "dgtd_layernorm_fwd");
     ctx->save_for_backward({x, w32, stats});
+    note_leaf(ctx, "leaf_w", w);
+    note_leaf(ctx, "leaf_b", b);
     return {y, x_};
   }
   static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -493,7 +552,7 @@ struct LayerNormForkFn : public torch::autograd::Function<LayerNormForkFn> {
     Tensor dx = at::empty_like(x);
     Tensor dgb = at::empty({2, C}, x.options().dtype(at::kFloat));
     Tensor ws = at::empty({dgtd_layernorm_bwd_workspace((int)C) / 4}, x.options().dtype(at::kFloat));
-    if (deferring()) {
+    if (may_defer(ctx, "leaf_w") && may_defer(ctx, "leaf_b")) {
       int nb = 0;
       check(dgtd_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), w32.data_ptr<float>(), stats.data_ptr<float>(), stats.data_ptr<float>() + rows,
                                        dres.defined() ? dres.data_ptr() : nullptr, dx.data_ptr(), ws.data_ptr(), rows, (int)C, code(x), &nb, stream()),
@@ -559,15 +618,15 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
 // weight / bias gradient of a depthwise convolution: first stage into per-workgroup partial rows { dw_t | db }, then ONE multi-reduce
 // entry that also transposes into the Conv2d layout and converts to the parameters' dtype (was: reduce + unpack, two launches) - parked
 // with the other column reductions of the backward pass when the reducer has switched deferral on.
-inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias, int64_t C, int64_t K, Tensor& dw, Tensor& db) {
+inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias, int64_t C, int64_t K, Tensor& dw, Tensor& db, bool defer) {
   const int64_t KK = K * K;
   static const bool batch_dw = [] { const char* e = std::getenv("DGTD_DEFER_DWCONV"); return !e || std::atoi(e) != 0; }();
-  if (deferring() && batch_dw) { park_dw(x, du, dw, db, has_bias, (int)C, (int)K); return; }
+  if (defer && batch_dw) { park_dw(x, du, dw, db, has_bias, (int)C, (int)K); return; }
   Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K) / 4}, x.options().dtype(at::kFloat));
   int nb = 0;
   check(dgtd_dwconv_bwd_weight_partial(x.data_ptr(), du.data_ptr(), has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
                                        (int)C, (int)K, code(x), &nb, stream()), "dgtd_dwconv_bwd_weight_partial");
-  if (deferring()) {
+  if (defer) {
     park(ws, nb, (int)((KK + 1) * C), nullptr, 0, dw.data_ptr(), code(dw), (int)KK, (int)C, has_bias ? db.data_ptr() : nullptr);
   } else {
     const dgtd_reduce_entry e{ws.data_ptr<float>(), nb, (int32_t)((KK + 1) * C), nullptr, 0, dw.data_ptr(), (int32_t)code(dw), (int32_t)KK, (int32_t)C,
@@ -600,6 +659,8 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
     Tensor y = launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, gelu ? 1 : 0, (int)K,
                       (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, x.sizes(), x.options()) : Tensor());
     ctx->saved_data["hint"] = hint_iv(ar ? hint : Hint{}, groles.first);
+    note_leaf(ctx, "leaf_w", weight_);
+    if (has_bias) note_leaf(ctx, "leaf_b", *bias_);
     ctx->save_for_backward({x, packed});
     ctx->saved_data["gelu"] = gelu;
     ctx->saved_data["K"] = K;
@@ -624,7 +685,7 @@ struct DwConvFn : public torch::autograd::Function<DwConvFn> {
                        (hint.group >= 0 && ra >= 0 && deferring()) ? arena_slot(hint, ROLE_DY + ra, x.sizes(), x.options()) : Tensor());
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
-    dwconv_weight_grads(x, du, has_bias, C, K, dw, db);
+    dwconv_weight_grads(x, du, has_bias, C, K, dw, db, may_defer(ctx, "leaf_w") && (!has_bias || may_defer(ctx, "leaf_b")));
     return {dx, dw, db, undefined()};
   }
 };
@@ -642,6 +703,8 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     Tensor packed = packed_dw(weight, bias, has_bias, C, K);
     const float* base = packed.data_ptr<float>();
     Tensor y = DwConvFn::launch(x, base, has_bias ? base + 2 * KK * C : nullptr, nullptr, 0, (int)K);
+    note_leaf(ctx, "leaf_w", weight_);
+    if (has_bias) note_leaf(ctx, "leaf_b", *bias_);
     ctx->save_for_backward({x, packed});
     ctx->saved_data["K"] = K;
     ctx->saved_data["has_bias"] = has_bias;
@@ -663,7 +726,7 @@ struct DwConvForkFn : public torch::autograd::Function<DwConvForkFn> {
     Tensor dx = skip.defined() ? DwConvFn::launch(du, base + KK * C, nullptr, &skip, 3, (int)K) : DwConvFn::launch(du, base + KK * C, nullptr, nullptr, 0, (int)K);
     Tensor dw = at::empty({C, 1, K, K}, x.options().dtype(wdtype));
     Tensor db = has_bias ? at::empty({C}, x.options().dtype(wdtype)) : Tensor();
-    dwconv_weight_grads(x, du, has_bias, C, K, dw, db);
+    dwconv_weight_grads(x, du, has_bias, C, K, dw, db, may_defer(ctx, "leaf_w") && (!has_bias || may_defer(ctx, "leaf_b")));
     return {dx, dw, db};
   }
 };
@@ -705,12 +768,12 @@ struct ScaleResidualFn : public torch::autograd::Function<ScaleResidualFn> {
 };
 
 // ------------------------------------------------------------------------------------------------ Linear (library GEMMs + colsum bias grad)
-Tensor colsum(const Tensor& x2, at::ScalarType out_dt) {
+Tensor colsum(const Tensor& x2, at::ScalarType out_dt, bool defer) {
   const int64_t rows = x2.size(0), C = x2.size(1);
   if (C % (16 / (int64_t)x2.element_size())) return at::sum(x2, {0}, false, at::kFloat).to(out_dt);   // narrower than a 16-byte chunk per lane
   Tensor out = at::empty({C}, x2.options().dtype(out_dt));
   Tensor ws = at::empty({dgtd_colsum_workspace((int)C) / 4}, x2.options().dtype(at::kFloat));
-  if (deferring()) {
+  if (defer) {
     int nb = 0;
     check(dgtd_colsum_partial(x2.data_ptr(), ws.data_ptr(), rows, (int)C, code(x2), &nb, stream()), "dgtd_colsum_partial");
     const bool f = out_dt == at::kFloat;
@@ -798,6 +861,8 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     const Hint hint = t_hint;
     const int xr = (hinted(hint, dt) && w.scalar_type() == dt) ? find_role(hint, ROLE_X, x2) : -1;
     ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
+    note_leaf(ctx, "leaf_w", w);
+    if (has_b) note_leaf(ctx, "leaf_b", *b_);
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_dt"] = st_id(w);
     ctx->saved_data["b_dt"] = has_b ? st_id(*b_) : (int64_t)-1;
@@ -813,7 +878,7 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     const Hint hint = hint_of(ctx->saved_data["hint"]);
     const int yr = (hint.group >= 0 && deferring()) ? find_role(hint, ROLE_DY, dy2) : -1;
     Tensor dw;
-    if (yr >= 0) {
+    if (yr >= 0 && may_defer(ctx, "leaf_w")) {
       dw = arena_slot(hint, ROLE_DW + yr, wc.sizes(), wc.options());
       park_gemm(hint, yr, x2, dy2, dw);
     } else {
@@ -823,7 +888,7 @@ struct LinearFn : public torch::autograd::Function<LinearFn> {
     }
     Tensor db;
     const int64_t bk = ctx->saved_data["b_dt"].toInt();
-    if (bk >= 0) db = colsum(dy2, (at::ScalarType)bk);
+    if (bk >= 0) db = colsum(dy2, (at::ScalarType)bk, may_defer(ctx, "leaf_b"));
     return {dx, dw, db, undefined()};
   }
 };
@@ -848,6 +913,8 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     at::gelu_out(h2, pre);
     const int xr = ar ? find_role(hint, ROLE_X, x2) : -1;
     ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
+    note_leaf(ctx, "leaf_w", w);
+    note_leaf(ctx, "leaf_b", b);
     ctx->save_for_backward({x2, wc, pre});
     ctx->saved_data["xshape"] = x.sizes().vec();
     ctx->saved_data["w_dt"] = st_id(w);
@@ -866,7 +933,7 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor dpre = ar ? arena_slot(hint, ROLE_DY + xr, pre.sizes(), pre.options()) : at::empty_like(pre);
     Tensor db = at::empty({C}, pre.options().dtype(st_of(ctx->saved_data["b_dt"])));
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, pre.options().dtype(at::kFloat));
-    if (deferring()) {
+    if (may_defer(ctx, "leaf_b")) {
       int nb = 0;
       check(dgtd_gelu_bias_bwd_partial(dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), ws.data_ptr(), rows, (int)C, code(pre), &nb, stream()),
             "dgtd_gelu_bias_bwd_partial");
@@ -878,7 +945,7 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor dx;
     if (ctx->saved_data["need_dx"].toBool()) dx = gemm_dx(dpre, wc).view(ctx->saved_data["xshape"].toIntVector());
     Tensor dw;
-    if (ar) {
+    if (ar && may_defer(ctx, "leaf_w")) {
       dw = arena_slot(hint, ROLE_DW + xr, wc.sizes(), wc.options());
       park_gemm(hint, xr, x2, dpre, dw);
     } else {
@@ -912,6 +979,9 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     const Hint hint = t_hint;
     const int xr = (hinted(hint, dt) && w.scalar_type() == dt) ? find_role(hint, ROLE_X, h2) : -1;
     ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
+    note_leaf(ctx, "leaf_w", w);
+    note_leaf(ctx, "leaf_b", b);
+    if (has_g) note_leaf(ctx, "leaf_g", *gamma_);
     ctx->saved_data["hshape"] = h.sizes().vec();
     ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, st_id(w), st_id(b), has_g ? st_id(*gamma_) : (int64_t)at::kFloat,
                                                    h.requires_grad(), B};
@@ -934,7 +1004,7 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
     Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, y.options().dtype(at::kFloat));
     // the layer-scale gradient is deferred only when it needs no dtype conversion afterwards (gamma is an fp32 parameter on this path)
-    if (deferring() && (!has_g || g_dt == at::kFloat)) {
+    if ((!has_g || (g_dt == at::kFloat && may_defer(ctx, "leaf_g"))) && may_defer(ctx, "leaf_b")) {
       int nb = 0;
       check(dgtd_scale_residual_bias_bwd_partial(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr,
                                                  has_g ? g32.data_ptr<float>() : nullptr, dy.data_ptr(), ws.data_ptr(), rows, (int)C, rows / B,
@@ -948,7 +1018,7 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     Tensor dh;
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
     Tensor dw;
-    if (ar) {
+    if (ar && may_defer(ctx, "leaf_w")) {
       dw = arena_slot(hint, ROLE_DW + xr, wc.sizes(), wc.options());
       park_gemm(hint, xr, h2, dy, dw);
     } else {
@@ -1042,6 +1112,8 @@ struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
     ctx->saved_data["need_dx"] = x_.requires_grad();
     ctx->saved_data["defer"] = conv_register(w_, w, ConvKey{g.B, g.H, g.W, g.Ci, g.Co, (int)code(x)}) &&
                                (!has_b || (b_->requires_grad() && !b_->grad_fn() && b_->data_ptr() == b.data_ptr()));
+    note_leaf(ctx, "leaf_w", w_);
+    if (has_b) note_leaf(ctx, "leaf_b", *b_);
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -1052,7 +1124,9 @@ struct Conv3x3ClFn : public torch::autograd::Function<Conv3x3ClFn> {
     Tensor dy = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
     Tensor dx = need_dx ? at::empty_like(x) : Tensor();
     Tensor dw, db;
+    // first call of this weight in the backward pass: its leaf (and bias) must not own a gradient yet; later calls share the destination
     const bool parked = ctx->saved_data["defer"].toBool() && deferring() &&
+                        (conv_dest_exists(w) || !(leaf_has_grad(ctx, "leaf_w") || (has_b && leaf_has_grad(ctx, "leaf_b")))) &&
                         conv_park(x, dy, ym, w, ConvKey{g.B, g.H, g.W, g.Ci, g.Co, (int)code(x)}, has_b, dw, db);
     if (!parked) { dw = at::empty_like(w); db = has_b ? at::empty({g.Co}, w.options()) : Tensor(); }
     conv3x3_backward_raw(x, w, ym, dy, g, need_dx, has_b, dx, dw, db, parked);
@@ -1073,6 +1147,7 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     ctx->save_for_backward({x, a32});
     ctx->saved_data["a_dt"] = st_id(a);
     ctx->saved_data["a_key"] = (a.requires_grad() && !a.grad_fn()) ? (int64_t)(intptr_t)a.data_ptr() : (int64_t)0;
+    note_leaf(ctx, "leaf_a", a);
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -1082,7 +1157,13 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     if (g.scalar_type() != x.scalar_type() || g.strides() != x.strides()) g = at::empty_like(x).copy_(g);
     Tensor dx = at::empty_like(x);
     const void* key = (const void*)(intptr_t)ctx->saved_data["a_key"].toInt();
-    if (key && deferring() && g_shared_ok.load(std::memory_order_relaxed)) {
+    bool share = key && deferring() && g_shared_ok.load(std::memory_order_relaxed);
+    if (share) {
+      bool have;
+      { std::lock_guard<std::mutex> lk(g_pending_mu); have = g_prelu_acc.count(key) > 0; }
+      if (!have && leaf_has_grad(ctx, "leaf_a")) share = false;       // accumulation: the slope already owns a gradient
+    }
+    if (share) {
       Tensor acc, ret;
       {
         std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -1212,4 +1293,5 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("arena_roles(int out, int grad_a, int grad_b) -> ()", &arena_roles);
   m.def("arena_release(int group) -> ()", &arena_release);
   m.def("arena_bytes() -> int", &arena_bytes);
+  m.def("arena_pin(bool on) -> ()", &arena_pin);
 }

@@ -33,11 +33,14 @@ def init_process_group(backend: Optional[str] = None) -> tuple:
     """One process per GPU; rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("DGTD_DIST_BACKEND") == "gloo" and torch.cuda.is_available() and torch.cuda.device_count() == 1:
+        local = 0      # several gloo ranks sharing the one GPU of a test box
     # DGTD_FORCE_ALLREDUCE=1: rehearse the RCCL path (process group, side-stream all-reduce) with a single rank on a one-GPU box
     if (world > 1 or os.environ.get("DGTD_FORCE_ALLREDUCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # DGTD_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of the multi-rank control flow on a one-GPU box; RCCL needs a GPU per rank)
+        backend = backend or os.environ.get("DGTD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -101,6 +104,15 @@ class GradReducer:
             self._seal(cur, castable)
         self._force = os.environ.get("DGTD_FORCE_ALLREDUCE") == "1" and dist.is_initialized()
         self.overlap = overlap and (self.world > 1 or self._force)
+        # N > 1: the working-copy segment of a bucket travels in the WORKING dtype (its leaf gradients are 16-bit tensors already, so
+        # the gather into a 16-bit buffer is lossless; 228.8 MB instead of 457.7 MB over xGMI at config 2) and is widened into the
+        # fp32 bucket on the comm stream right after its all-reduce.  DGTD_COMM_FP32=1 keeps the fp32 payload.
+        self.comm16 = (self.working_dtype is not None and (self.world > 1 or self._force)
+                       and os.environ.get("DGTD_COMM_FP32", "0") != "1")
+        if self.comm16:
+            for b in self.buckets:
+                if b["n_work"]:
+                    b["g16"] = torch.zeros(b["n_work"], dtype=self.working_dtype, device=b["flat"].device)
         self._cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self._cuda and self.overlap) else None
         self._works, self._next = [], 0
@@ -168,7 +180,7 @@ class GradReducer:
                              "masters": masters, "leaves": leaves, "gviews": gviews, "nhwc": nhwc, "offsets": offsets,
                              "names": [n_ for n_, _ in work + rest], "sizes": [p_.numel() for _, p_ in work + rest],
                              "padded": [pad_to(p_.numel()) for _, p_ in work + rest], "shapes": [tuple(p_.shape) for _, p_ in work + rest],
-                             "modules": modules, "missing": (), "pads": {},
+                             "modules": modules, "missing": (), "pads": {}, "g16": None,
                              "pending": len(items), "n": len(items), "done": False, "ready": False, "index": len(self.buckets)})
 
     # ------------------------------------------------------------------ per step
@@ -263,21 +275,26 @@ class GradReducer:
             return g.permute(0, 2, 3, 1).reshape(-1) if cl else g.reshape(-1)
 
         missing = []
+        g16 = bucket["g16"]
 
-        def seg(lo, hi, out):
+        def seg(lo, hi, out, base):
+            """leaves[lo:hi] -> out (flat fp32 slice, or the 16-bit communication buffer of the working-copy segment);
+            ``base`` = offset of ``out`` inside the bucket."""
             if lo == hi:
                 return
             gs = [l.grad for l in leaves[lo:hi]]
-            if any(g is None for g in gs):   # a parameter unused this step: per-tensor copies; FlatAdamW skips its slot like torch.optim.AdamW skips grad None
-                for i, (g, gv) in enumerate(zip(gs, gviews[lo:hi])):
+            offs = bucket["offsets"]
+            if any(g is None for g in gs):   # a parameter unused this step: per-tensor copies; its slot is zero (world 1: FlatAdamW skips it like torch.optim.AdamW skips grad None)
+                for i, (g, c) in enumerate(zip(gs, nhwc[lo:hi])):
+                    dst = out[offs[lo + i] - base: offs[lo + i] - base + sizes[lo + i]]
                     if g is None:
-                        gv.zero_()
+                        dst.zero_()
                         missing.append(lo + i)
                     else:
-                        gv.copy_(g)
+                        dst.copy_(flat1d(g, c))
                 return
             if flat.is_cuda:
-                # ONE launch per 128 tensors and dtype: 16-bit gradient -> fp32 bucket slot directly (no concat + cast), table by value
+                # ONE launch per 128 tensors and dtype: 16-bit gradient -> bucket slot directly (no concat + cast), table by value
                 # in the kernel arguments (hipGraph-safe; torch.cat on ROCm is not, csrc/multicopy.hip).  Padding slots are never
                 # written and stay zero.
                 from .. import _lib as L
@@ -286,9 +303,9 @@ class GradReducer:
                     v = flat1d(g, c)
                     by_dtype.setdefault(v.dtype, ([], []))
                     by_dtype[v.dtype][0].append(v if v.is_contiguous() else v.contiguous())
-                    by_dtype[v.dtype][1].append(bucket["offsets"][lo + i])
-                for ts, offs in by_dtype.values():
-                    L.multi_copy(ts, offs, flat)
+                    by_dtype[v.dtype][1].append(offs[lo + i] - base)
+                for ts, os_ in by_dtype.values():
+                    L.multi_copy(ts, os_, out)
                 return
             parts = []
             for i, (g, c) in enumerate(zip(gs, nhwc[lo:hi])):
@@ -300,8 +317,8 @@ class GradReducer:
             else:
                 out.copy_(torch.cat(parts))
 
-        seg(0, k, flat[:nw])
-        seg(k, len(leaves), flat[nw:])
+        seg(0, k, g16 if g16 is not None else flat[:nw], 0)
+        seg(k, len(leaves), flat[nw:], nw)
         bucket["missing"] = tuple(missing)
         for p, leaf, gv in zip(bucket["masters"], leaves, gviews):
             leaf.grad = None            # free the per-leaf gradient
@@ -311,21 +328,33 @@ class GradReducer:
     def _launch(self, bucket) -> None:
         if self.world == 1 and not self._force:
             return
-        flat = bucket["flat"]
+        flat, g16, nw = bucket["flat"], bucket["g16"], bucket["n_work"]
         # RCCL averages inside the collective (ReduceOp.AVG); gloo (CPU tests) has no AVG: scale, then sum
         avg = dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        # payload: [16-bit working-copy segment] + [fp32 rest], or the whole fp32 bucket
+        parts = [flat] if g16 is None else ([g16] + ([flat[nw:]] if flat.numel() > nw else []))
+
+        def go():
+            ws = []
+            for t in parts:
+                if not avg:
+                    t.div_(self.world)
+                ws.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+            if g16 is not None:     # widen into the fp32 bucket the optimizer reads
+                if not avg:         # gloo: completion is not stream-ordered, join before reading the result
+                    for w in ws:
+                        w.wait()
+                    ws = []
+                flat[:nw].copy_(g16)   # RCCL: same stream as the all-reduce, ordered after it
+            self._works.extend(ws)
+
         if self._cuda and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                if not avg:
-                    flat.div_(self.world)
-                w = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+                go()
         else:
-            if not avg:
-                flat.div_(self.world)
-            w = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
-        self._works.append(w)
+            go()
 
     def finish(self) -> None:
         """Call after backward(): gathers/launches whatever the hooks did not (in bucket order), then fences the compute stream."""

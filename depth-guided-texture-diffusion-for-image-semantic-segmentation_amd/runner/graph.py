@@ -15,7 +15,9 @@ call.  What had to be true for capture to be correct (the round-1 attempt crashe
   once after backward, inside the capture);
 * no torch.cat / torch.stack in the captured region (see ``_no_cat``): that, not the autograd engine, was what made the round-1
   replays produce NaNs;
-* world > 1: the all-reduce stays OUTSIDE the graphs (graph A = forward/backward/gather, eager bucketed all-reduce, graph B = AdamW).
+* world > 1: with RCCL the bucketed all-reduces are captured too, forked onto the reducer's side stream from the autograd hooks
+  (one graph, collectives overlapped with the rest of backward); with a backend that cannot be captured (gloo) the all-reduce stays
+  OUTSIDE the graphs (graph A = forward/backward/gather, eager bucketed all-reduce, graph B = AdamW).
 """
 from __future__ import annotations
 
@@ -45,16 +47,41 @@ class _no_cat:
 
 
 class GraphedTrainStep:
-    def __init__(self, net, reducer, opt, scaler=None, warmup: int = 3):
+    """``comm`` decides how the gradient all-reduce of an N > 1 job meets the captured step:
+
+    * ``"fused"``: the bucketed all-reduces are captured INSIDE the one graph, on the reducer's side stream: the autograd hooks gather
+      a bucket when its last gradient arrives and fork the collective (event edges comm_stream <- capture stream), ``finish()`` joins
+      it before AdamW.  The replayed graph then has the RCCL kernels as a parallel branch beside the rest of the backward pass - the
+      overlap of the eager mode without its host cost.  Needs a backend whose collectives are stream-ordered and capturable (RCCL).
+    * ``"split"``: graph A (forward / backward / gather) -> eager bucketed all-reduce -> graph B (AdamW); no overlap, works with any
+      backend (the gloo tests).
+    * ``"auto"``: fused with RCCL, split otherwise.  World 1 without DGTD_FORCE_ALLREDUCE: one graph, no collective.
+
+    The eager warm-up steps that precede capture (handles, plans, AccumulateGrad nodes on the capture stream) run on the first batch;
+    parameters, optimizer state, BatchNorm statistics, the loss scale and the RNG are snapshotted before and restored after them, so a
+    captured run is step-equivalent to an eager one (``restore_after_warmup=False`` keeps them as extra training steps)."""
+
+    def __init__(self, net, reducer, opt, scaler=None, warmup: int = 3, comm: str = "auto", restore_after_warmup: bool = True):
         if not getattr(opt, "graph_safe", False):
             raise ValueError("GraphedTrainStep needs FlatAdamW(graph_safe=True): bias corrections and learning rates in device memory")
         self.net, self.reducer, self.opt, self.scaler, self.warmup = net, reducer, opt, scaler, warmup
+        self.restore = restore_after_warmup
         self.stream = torch.cuda.Stream()
-        self.graph_fb: Optional[torch.cuda.CUDAGraph] = None      # forward + backward + gather (+ AdamW when world == 1)
-        self.graph_opt: Optional[torch.cuda.CUDAGraph] = None     # AdamW alone (world > 1)
+        self.graph_fb: Optional[torch.cuda.CUDAGraph] = None      # forward + backward + gather (+ all-reduce + AdamW unless split)
+        self.graph_opt: Optional[torch.cuda.CUDAGraph] = None     # AdamW alone (split mode)
         self.static = None
         self.loss = None
-        self.split = reducer.world > 1 or reducer._force
+        multi = reducer.world > 1 or reducer._force
+        if comm not in ("auto", "fused", "split"):
+            raise ValueError(f"comm must be auto, fused or split, got {comm!r}")
+        if not multi:
+            self.mode = "single"
+        elif comm == "auto":
+            import torch.distributed as dist
+            self.mode = "fused" if dist.get_backend(reducer.group) == "nccl" else "split"
+        else:
+            self.mode = comm
+        self.split = self.mode == "split"
 
     # ------------------------------------------------------------------ pieces
     def _stage(self, batch) -> None:
@@ -93,42 +120,109 @@ class GraphedTrainStep:
         if r.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(r.comm_stream)
 
+    def _one_step(self) -> torch.Tensor:
+        """The step in the order the capture records it (also the eager warm-up)."""
+        loss = self._fwd_bwd()
+        if self.mode == "fused":
+            self.reducer.finish()          # hooks gathered + launched during backward; stragglers, join, fence
+        else:
+            self._gather_all()
+            if self.split:
+                self._allreduce_all()
+        self.opt.step()
+        return loss
+
+    # ------------------------------------------------------------------ state around the warm-up
+    def _snapshot(self):
+        r, o = self.reducer, self.opt
+        snap = {"buckets": [(b["mflat"].clone(), None if b["wflat"] is None else b["wflat"].clone()) for b in r.buckets],
+                "moments": [(st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for st in o.state],
+                "opt_state": None if o._state is None else o._state.clone(), "steps": o._steps,
+                "buffers": [(bf, bf.clone()) for bf in self.net.buffers()],
+                "rng": torch.cuda.get_rng_state(), "cpu_rng": torch.get_rng_state()}
+        return snap
+
+    @torch.no_grad()
+    def _restore(self, snap) -> None:
+        r, o = self.reducer, self.opt
+        for b, (m, w) in zip(r.buckets, snap["buckets"]):
+            b["mflat"].copy_(m)
+            if w is not None:
+                b["wflat"].copy_(w)
+        for st, (m, v) in zip(o.state, snap["moments"]):
+            st["exp_avg"].copy_(m)
+            st["exp_avg_sq"].copy_(v)
+        if snap["opt_state"] is not None:
+            o._state.copy_(snap["opt_state"])
+        o._steps = snap["steps"]
+        for bf, v in snap["buffers"]:
+            bf.copy_(v)
+        torch.cuda.set_rng_state(snap["rng"])
+        torch.set_rng_state(snap["cpu_rng"])
+
     # ------------------------------------------------------------------ capture
     def capture(self, batch) -> None:
         dev = next(self.net.parameters()).device
         stack = lambda v: (torch.stack(list(v)) if isinstance(v, (list, tuple)) else v).to(dev)
         self.static = {k: stack(batch[k]).clone() for k in ("input", "label", "depth")}
         self.static["x_hp"] = torch.empty_like(self.static["input"], dtype=torch.float32)
-        overlap, self.reducer.overlap = self.reducer.overlap, False          # hooks only count; gather/launch are explicit below
+        r = self.reducer
+        overlap = r.overlap
         self._overlap_before = overlap
-        s = self.stream
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(self.warmup):                                     # eager, on the capture stream
+        # fused: hooks gather + fork the collectives (eager overlap mode, recorded); otherwise hooks only count and gather / launch
+        # are explicit in _one_step
+        r.overlap = overlap if self.mode == "fused" else False
+        try:
+            s = self.stream
+            s.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            snap = self._snapshot() if (self.restore and self.warmup > 0) else None
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):                                     # eager, on the capture stream
+                    self._stage(batch)
+                    self._one_step()
+                if snap is not None:
+                    self._restore(snap)
                 self._stage(batch)
-                self._fwd_bwd()
-                self._gather_all()
+                r.zero_grad()                                                    # every leaf .grad is None when capture starts
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph_fb = torch.cuda.CUDAGraph()
+            # with a process group alive, RCCL's watchdog thread keeps querying events while we capture: only this thread's (and the
+            # autograd thread's, which launches into the capturing stream) calls must obey capture rules
+            mode = "global" if self.mode == "single" else "thread_local"
+            with _no_cat(), torch.cuda.graph(self.graph_fb, stream=s, capture_error_mode=mode):
                 if self.split:
-                    self._allreduce_all()
-                self.opt.step()
-            self._stage(batch)
-            self.reducer.zero_grad()                                         # every leaf .grad is None when capture starts
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph_fb = torch.cuda.CUDAGraph()
-        # with a process group alive, RCCL's watchdog thread keeps querying events while we capture: only this thread's (and the
-        # autograd thread's, which launches into the capturing stream) calls must obey capture rules
-        mode = "thread_local" if self.split else "global"
-        with _no_cat(), torch.cuda.graph(self.graph_fb, stream=s, capture_error_mode=mode):
-            self.loss = self._fwd_bwd()
-            self._gather_all()
-            if not self.split:
-                self.opt.step()
-        if self.split:
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, stream=s, pool=self.graph_fb.pool(), capture_error_mode=mode):
-                self.opt.step()
-        torch.cuda.synchronize()
+                    self.loss = self._fwd_bwd()
+                    self._gather_all()
+                else:
+                    self.loss = self._one_step()
+            if self.split:
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt, stream=s, pool=self.graph_fb.pool(), capture_error_mode=mode):
+                    self.opt.step()
+            torch.cuda.synchronize()
+        except BaseException:
+            self.graph_fb = self.graph_opt = None
+            r._works.clear()
+            raise
+        finally:
+            r.overlap = overlap          # eager steps after (or instead of) the capture keep the reducer's own mode
+        self._pin_arenas(True)
+
+    def _pin_arenas(self, on: bool) -> None:
+        """The captured graph holds raw addresses of the per-stage arenas (csrc_torch/bindings.cpp): while pinned, a request that would
+        re-allocate one (an eager grad-enabled step with another batch shape) raises instead of letting the next replay write freed
+        memory."""
+        from ..ops import _native
+        nat = _native.ops()
+        if nat is not None and hasattr(nat, "arena_pin"):
+            nat.arena_pin(on)
+
+    def release(self) -> None:
+        """Drop the graphs (and un-pin the arenas they referenced)."""
+        self.graph_fb = self.graph_opt = None
+        self._pin_arenas(False)
 
     # ------------------------------------------------------------------ replay
     def __call__(self, batch) -> torch.Tensor:

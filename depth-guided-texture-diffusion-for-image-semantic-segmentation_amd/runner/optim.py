@@ -157,7 +157,10 @@ class FlatAdamW:
         lrp = self._lr_dev.data_ptr() if self._lr_dev is not None else None
         for b, slots, runs, state in zip(self.reducer.buckets, self.slots, self.runs, self.state):
             p, g, m, v, w, nw = b["mflat"], b["flat"], state["exp_avg"], state["exp_avg_sq"], b["wflat"], b["n_work"]
-            if b["missing"]:                        # parameters without a gradient this step are skipped, like torch.optim.AdamW does
+            # world 1: parameters without a gradient this step are skipped, like torch.optim.AdamW does.  N > 1: ``missing`` is
+            # rank-local while the all-reduced slot holds the average over every rank (zero from the ranks that did not use the
+            # parameter) - every rank applies the same update, so the replicas cannot drift apart
+            if b["missing"] and self.reducer.world == 1:
                 runs = self._merge(slots, nw, set(b["missing"]))
             for lo, hi, gi in runs:
                 wp = (w.data_ptr() + 2 * lo) if (w is not None and hi <= nw) else None

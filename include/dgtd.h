@@ -41,6 +41,8 @@ const char* dgtd_last_error(void);
  * the buffer size the full text needs.  The only mutable global state of the library, behind a mutex, inert unless enabled.      */
 int dgtd_profile_enable(int on);
 int64_t dgtd_profile_dump(char* buf, int64_t cap);
+/* an EMPTY bracket under key "dgtd_profile_empty": the event pair's own floor, which bench.py subtracts from every per-call figure */
+int dgtd_profile_empty(dgtd_stream stream);
 
 /* ---- LayerNorm over the last dim of a [rows, C] token matrix ---------------------------------
  * replaces nn.LayerNorm / F.layer_norm at twig/model/cod.py:979,881,929,936,1367-1391,1043.

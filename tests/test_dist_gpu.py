@@ -74,3 +74,152 @@ def test_reducer_streams_and_hooks_two_ranks_one_gpu():
         assert np.array_equal(a, b) and np.isfinite(a).all() and np.abs(a).sum() > 0   # same averaged gradient on both ranks
     for a, b in zip(res[0][1], res[1][1]):
         assert np.array_equal(a, b)                                                      # replicas stay in lock-step
+
+
+# ------------------------------------------------------------------------------------------------ the real model, two ranks
+def _cod_worker(rank, world, port, q, mode):
+    """One rank of a 2-rank job on the shared GPU: the real dgtd.nn.cod at 64x64, bf16 working copies, reducer + FlatAdamW.
+    mode: 'eager' = hooks gather + all-reduce buckets during backward (overlap on the side stream);
+          'split' = GraphedTrainStep, graph A | bucketed all-reduce | graph B (gloo cannot be captured)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import dgtd
+        from oracle import filler
+        torch.cuda.set_device(0)
+        dgtd.dist.init_process_group("gloo")
+        S, B = 64, 2
+        net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+        filler.fill_module(net)
+        net = net.cuda().train()
+        dgtd.dist.broadcast_parameters(net)
+        red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
+        assert red.world == 2 and red.comm16 and len(red.buckets) >= 4 and red.comm_stream is not None
+        opt = dgtd.runner.FlatAdamW(red, lr=1e-4, graph_safe=True)
+        x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))     # every rank its own samples
+        batch = {"raw": None, "input": x, "label": l, "depth": d}
+        losses = []
+        if mode == "eager":
+            for _ in range(2):
+                red.zero_grad()
+                loss = net(None, x, l, d, mode="loss")["loss"]
+                loss.backward()
+                red.finish()
+                if len(losses) == 0:
+                    torch.cuda.synchronize()
+                    grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in net.named_parameters() if p.grad is not None}
+                opt.step()
+                losses.append(loss.item())
+        else:
+            stepper = dgtd.runner.GraphedTrainStep(net, red, opt, warmup=1, comm="split")
+            stepper.capture(batch)
+            assert stepper.mode == "split" and stepper.graph_opt is not None
+            for _ in range(2):
+                losses.append(stepper(batch).item())
+                if len(losses) == 1:
+                    torch.cuda.synchronize()
+                    grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in net.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        weights = {n: p.detach().float().cpu().numpy().copy() for n, p in net.named_parameters()}
+        bn = net.hitnet.Translayer2_1.bn.running_mean.detach().cpu().numpy().copy()
+        q.put((rank, (grads, weights, losses, bn), None))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc(), None))
+        raise
+
+
+def _single_process_reference():
+    """world 1, same weights: the gradient of the MEAN of the two ranks' losses = the mean of the per-rank gradients, each rank's
+    batch through its own forward (BatchNorm statistics are per rank in the reference: plain BatchNorm2d, cod.py:362)."""
+    import dgtd
+    from oracle import filler
+    S, B = 64, 2
+    acc, losses = None, []
+    for rank in range(2):
+        net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+        filler.fill_module(net)
+        net = net.cuda().train()
+        red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
+        x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))
+        red.zero_grad()
+        loss = net(None, x, l, d, mode="loss")["loss"]
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        g = {n: p.grad.detach().float().cpu().numpy() / 2 for n, p in net.named_parameters() if p.grad is not None}
+        acc = g if acc is None else {n: acc[n] + g[n] for n in acc}
+        losses.append(loss.item())
+        del net, red
+    return acc, losses
+
+
+@pytest.mark.parametrize("mode", ["eager", "split"])
+def test_real_model_two_ranks_one_gpu(mode):
+    """the product's own modules (16-bit working copies, O,H,W,I gradient views, deferred weight gradients flushed
+    from inside the hooks, 16-bit all-reduce payload) under a 2-rank reducer: both ranks hold the same averaged gradient, it equals the
+    single-process mean of the per-rank gradients within the bf16 budget, replicas stay in lock-step after AdamW, BN statistics stay
+    per rank - once with hook-driven overlap, once through the captured split step."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cod_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, payload, _ = q.get(timeout=900)
+        assert not isinstance(payload, str), f"rank {r}: {payload}"
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (g0, w0, l0, bn0), (g1, w1, l1, bn1) = res[0], res[1]
+    assert set(g0) == set(g1) and len(g0) > 800
+    for n in g0:
+        assert np.array_equal(g0[n], g1[n]), n                       # the all-reduced gradient is the same tensor on both ranks
+        assert np.isfinite(g0[n]).all(), n
+    for n in w0:
+        assert np.array_equal(w0[n], w1[n]), n                       # replicas in lock-step after two optimizer steps
+    assert not np.array_equal(bn0, bn1)                              # BatchNorm statistics are per rank (no SyncBN in the reference)
+    want, lref = _single_process_reference()
+    assert abs(l0[0] - lref[0]) < 2e-2 * abs(lref[0]) and abs(l1[0] - lref[1]) < 2e-2 * abs(lref[1]), (l0, l1, lref)
+    # element-level agreement with the single-process mean gradient: bf16 payload + bf16 atomics noise
+    num = den = 0.0
+    worst = (0.0, None)
+    for n in want:
+        a, b = g0[n].astype(np.float64), want[n].astype(np.float64)
+        e, m = float(((a - b) ** 2).sum()), float((b ** 2).sum())
+        num, den = num + e, den + m
+        if m > 1e-12 and e / m > worst[0]:
+            worst = (e / m, n)
+    rel = (num / den) ** 0.5
+    print(f"[{mode}] 2-rank vs single-process mean gradient: global rel L2 {rel:.4f} (budget 0.03), worst tensor {worst[1]} {worst[0] ** 0.5:.3f}")
+    assert rel < 0.03, (rel, worst)
+
+
+def test_bench_control_flow_two_ranks_one_gpu(tmp_path):
+    """`bench.py --gpus N` had never run with N > 1 - rank 0 alone entered the instrumented pass (eager steps
+    with bucketed all-reduces) while the others went to the barrier.  Two gloo ranks on the one GPU run the whole script at a small
+    size: graph capture (split mode: gloo cannot be captured), timed steps, the instrumented pass on EVERY rank, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGTD_DIST_BACKEND="gloo", DGTD_GEMM_CANDIDATES="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "64", "--batch", "2", "--profile-steps", "1"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1100)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    assert out["config"]["hip_graph"] and out["config"]["graph_mode"] == "split", out["config"]
+    assert out["config"]["allreduce_payload"].startswith("16-bit")
+    assert out["value"] > 0 and out["roofline"] is not None and out["entries"], out
+    assert np.isfinite(out["config"]["final_loss"])

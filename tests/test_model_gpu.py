@@ -129,8 +129,11 @@ def test_bf16_mode_close_to_oracle(dgtd):
     ref = g["eval.P1"][-1] + g["eval.P2"]
     # bf16 (8-bit mantissa) through 16 + 36 blocks; the logits span [-2.9, 2.9].  Measured: max 0.10, mean 0.032, and no
     # label flips for |logit| >= 0.05.
-    assert np.abs(logit - ref).max() < 0.25
-    assert np.abs(logit - ref).mean() < 0.06
+    # budgets = 1.5 x the measured values; a regression of half that size fails
+    emax, emean = float(np.abs(logit - ref).max()), float(np.abs(logit - ref).mean())
+    print(f"bf16 eval logits vs reference golden: max |diff| {emax:.4f} (budget 0.15), mean {emean:.4f} (budget 0.048)")
+    assert emax < 0.15
+    assert emean < 0.048
     band = np.abs(ref) < 0.1
     assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])
 
@@ -379,6 +382,9 @@ def test_upstream_gradients_against_fp64_reference(dgtd):
         assert e_hip <= max(10.0 * e_cpu, 2e-3), (k, e_hip, e_cpu)
 
 
+POOLED_BUDGET = {torch.bfloat16: 0.15, torch.float16: 0.05}      # <= 1.5 x the measured pooled error (printed by the test)
+
+
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16], ids=str)
 def test_16bit_training_gradients_vs_oracle(dgtd, half):
     """the benchmarked precision had no gradient check.  The PRODUCTION configuration (16-bit working copies in
@@ -408,6 +414,11 @@ def test_16bit_training_gradients_vs_oracle(dgtd, half):
         cos = float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
         rows.append((k, nb, rel, cos))
     mass = sum(nb * nb for _, nb, _, _ in rows)
+    # one number for the whole gradient: relative L2 of all tensors pooled (dominated by the heavy ConvNeXt / PVT weights)
+    pooled = (sum((rel * nb) ** 2 for _, nb, rel, _ in rows) / mass) ** 0.5
+    pooled_budget = POOLED_BUDGET[half]
+    print(f"{half}: pooled relative L2 of the whole gradient {pooled:.4f} (budget {pooled_budget})")
+    assert pooled < pooled_budget, pooled
     budget = 0.15 if half == torch.bfloat16 else 0.05
     good = sum(nb * nb for _, nb, rel, _ in rows if rel < budget)
     worst = sorted(rows, key=lambda r: r[3])[:5]
@@ -415,6 +426,8 @@ def test_16bit_training_gradients_vs_oracle(dgtd, half):
     heavy = sorted([r for r in rows if r[2] >= budget], key=lambda r: -r[1])[:12]
     assert good / mass > 0.90, "fraction %.4f; heaviest tensors over budget (name, |g|, rel L2, cos):\n%s" % (good / mass, "\n".join(map(str, heavy)))
     floor = 1e-4 * total                                     # tensors whose whole gradient is below 1e-4 of the total are rounding noise
+    lowest = min(cos for _, nb, _, cos in rows if nb > floor)
+    print(f"{half}: lowest cosine above the noise floor {lowest:.4f} (budget > 0.9)")
     assert all(cos > 0.9 for _, nb, _, cos in rows if nb > floor), [r for r in rows if r[1] > floor and r[3] <= 0.9][:5]
 
 
@@ -430,8 +443,10 @@ def test_fp16_mode_close_to_oracle(dgtd):
     logit = (P1[-1] + P2).float().cpu().numpy()
     ref = g["eval.P1"][-1] + g["eval.P2"]
     assert np.isfinite(logit).all()
-    assert np.abs(logit - ref).max() < 0.06, np.abs(logit - ref).max()
-    assert np.abs(logit - ref).mean() < 0.015, np.abs(logit - ref).mean()
+    emax, emean = float(np.abs(logit - ref).max()), float(np.abs(logit - ref).mean())
+    print(f"fp16 eval logits vs reference golden: max |diff| {emax:.4f} (budget 0.06), mean {emean:.4f} (budget 0.015)")
+    assert emax < 0.06, emax
+    assert emean < 0.015, emean
     band = np.abs(ref) < 0.03
     assert np.array_equal((logit > 0)[~band], (ref > 0)[~band])
 

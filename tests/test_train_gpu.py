@@ -270,7 +270,8 @@ def test_fp16_training_tracks_bf16_loss_curve(dgtd, S, B):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=str)
 def test_graphed_step_matches_eager(dgtd, dtype):
     """the whole training step (forward + loss + backward + bucket gather + AdamW) captured as ONE hipGraph and
-    replayed must follow the eager step: same losses and weights over 3 steps after the same warm-up (fp32: to fp32-atomic noise;
+    replayed must follow the eager step: same losses and weights over 3 steps, the capture's eager warm-up steps leaving no trace
+    (parameters, moments, step counter, BatchNorm statistics are restored: ADVICE r2) (fp32: to fp32-atomic noise;
     bf16: finite and close), with the learning rate changed between replays (device-resident lr) and the optimizer's step count
     advancing on the device."""
     S, B, W = 64, 2, 2
@@ -295,9 +296,7 @@ def test_graphed_step_matches_eager(dgtd, dtype):
         opt.step()
         return loss.item()
 
-    net_e, red_e, opt_e = make()
-    for _ in range(W):
-        eager_step(net_e, red_e, opt_e, batches[0])
+    net_e, red_e, opt_e = make()     # no warm-up on the eager side: the captured step restores weights / moments / statistics after its own
     want = []
     for i in range(3):
         if i == 2:
@@ -321,7 +320,7 @@ def test_graphed_step_matches_eager(dgtd, dtype):
         junk.append(torch.cat([torch.randn(100, device="cuda") for _ in range(200)]))
         torch.cuda.synchronize()
         del junk
-    assert opt_g.steps == opt_e.steps == W + 3
+    assert opt_g.steps == opt_e.steps == 3
     tol = 1e-4 if dtype == torch.float32 else 2e-2      # fp32: atomic summation order in a few backward kernels
     for a_, b_ in zip(got, want):
         assert math.isfinite(a_) and abs(a_ - b_) <= tol * max(1.0, abs(b_)), (got, want)
@@ -421,3 +420,169 @@ def test_batched_weight_gradient_gemms_match_per_layer_path(dgtd):
         assert (a - b).norm() / b.norm() < 1e-2, k
     for k in grads[True]:
         torch.testing.assert_close(grads[True][k], grads[False][k], rtol=3e-2, atol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_step_with_forced_allreduce(dtype):
+    """VERDICT r2 next #1(b): the N > 1 forms of the captured step under a test.  A world-1 RCCL group (DGTD_FORCE_ALLREDUCE=1, own
+    process so the communicator never meets the other tests) runs 3 steps eager with hook-driven bucket all-reduces, then the same
+    through GraphedTrainStep in both N > 1 modes: "fused" (collectives captured inside the one graph on the side stream) and
+    "split" (graph A | all-reduce | graph B).  fp32: same losses / weights as eager to atomic noise; bf16 (16-bit payload): close."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_forced_allreduce_worker.py")
+    p = subprocess.run([sys.executable, worker, dtype, str(port)], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    for mode in ("fused", "split"):
+        got, want = out[mode]["losses"], out["eager"]["losses"]
+        print(f"[{dtype} {mode}] losses {got} vs eager {want}; max weight diff {out[mode]['max_weight_diff']:.2e}, elements off {out[mode]['elements_off']}")
+        assert out[mode]["steps"] == 3
+        for a_, b_ in zip(got, want):
+            assert math.isfinite(a_) and abs(a_ - b_) <= tol * max(1.0, abs(b_)), (mode, got, want)
+        if dtype == "f32":
+            assert out[mode]["max_weight_diff"] < 5e-4 and out[mode]["elements_off"] < 20000, out[mode]
+
+
+def _tiny_trunk(dgtd, dtype=torch.bfloat16):
+    """A bias-carrying Linear called TWICE, a LayerNorm, a depthwise conv and a fused Linear+residual: every deferring node family."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shared = dgtd.nn.Linear(64, 64)
+            self.norm = dgtd.nn.LayerNorm(64, eps=1e-6)
+            self.dw = dgtd.nn.DWConv(64)
+            self.out = dgtd.nn.Linear(64, 64)
+
+        def forward(self, x):                       # x [B, 64, 64] tokens of an 8x8 map
+            h = self.shared(self.shared(x))         # one weight / bias, two call sites
+            h = self.dw(self.norm(h), 8, 8, gelu=True)
+            return dgtd.ops.linear_residual(h, *dgtd.nn.wb(self.out), x, None)
+    torch.manual_seed(3)
+    return Net().cuda().train()
+
+
+@pytest.mark.parametrize("case", ["shared_bias", "two_backwards", "retain_graph"])
+def test_deferred_gradients_survive_accumulation(dgtd, case):
+    """ADVICE r2 (medium) / VERDICT r2 weak #4: deferred backward nodes hand autograd an UNWRITTEN tensor, which is sound only while
+    autograd steals it as .grad.  A parameter with two call sites, two backward() calls between zero_grad() and finish(), and a
+    second backward through a retained graph must all give the gradients of the deferral-off run (bit-level: same kernels, immediate
+    path) - not sums over uninitialised memory."""
+    from dgtd.dist import reducer as R
+    x = torch.randn(2, 64, 64, device="cuda")
+    grads = {}
+    for defer in (False, True):
+        R.DEFER = defer
+        try:
+            net = _tiny_trunk(dgtd)
+            red = dgtd.dist.GradReducer(net, exclude_prefixes=(), working_dtype=torch.bfloat16)
+            red.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(x.bfloat16())
+                loss = (y.float() ** 2).mean()
+                if case == "two_backwards":
+                    loss.backward()
+                    y2 = net(x.bfloat16() * 0.5)
+                    (y2.float() ** 2).mean().backward()
+                elif case == "retain_graph":
+                    loss.backward(retain_graph=True)
+                    loss.backward()
+                else:
+                    loss.backward()
+            red.finish()
+            torch.cuda.synchronize()
+            grads[defer] = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+        finally:
+            R.DEFER = True
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert torch.isfinite(a).all(), n
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-3 * float(b.abs().max()) + 1e-7, msg=lambda m, n=n: f"{case} {n}: {m}")
+
+
+def test_two_models_training_alternately_match_their_solo_runs(dgtd):
+    """VERDICT r2 next #5: the binding layer's registries are process-global; two models stepping alternately must not see each other."""
+    S, B = 64, 2
+    x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=11))
+
+    def make(seed):
+        net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.float32)
+        filler.fill_module(net)
+        with torch.no_grad():
+            net.hitnet.out_CFM.bias.add_(0.01 * seed)
+        net = net.cuda().train()
+        red = dgtd.dist.GradReducer(net)
+        return net, red, dgtd.runner.FlatAdamW(red, lr=1e-4)
+
+    def step(net, red, opt):
+        red.zero_grad()
+        loss = net(None, x, l, d, mode="loss")["loss"]
+        loss.backward()
+        red.finish()
+        opt.step()
+        return loss.item()
+
+    solo = []
+    for seed in (1, 2):
+        m = make(seed)
+        solo.append([step(*m) for _ in range(3)])
+        del m
+    a, b = make(1), make(2)
+    both = [[], []]
+    for _ in range(3):
+        both[0].append(step(*a))
+        both[1].append(step(*b))
+    for s_, t_ in zip(solo, both):
+        for u, v in zip(s_, t_):
+            assert abs(u - v) <= 1e-4 * max(1.0, abs(u)), (solo, both)
+
+
+def test_config5_fp16_b16_full_size_properties(dgtd):
+    """BASELINE config 5's per-GPU workload at full size: 512x512, batch 16, fp16 compute + fp32 masters + dynamic loss scaling
+    (config/cod.yml + AmpOptimWrapper), 6 steps.  Properties the size does not change: the loss is finite at every step, the scaler
+    stops overflowing after its warm-up (the initial 65536 may skip steps) and takes steps, every trunk ends with finite, non-zero
+    gradients, the masters move."""
+    torch.manual_seed(0)
+    S, B = 512, 16
+    net = dgtd.nn.cod(compute_dtype=torch.float16).cuda().train()
+    red = dgtd.dist.GradReducer(net, working_dtype=torch.float16)
+    scaler = dgtd.runner.LossScaler("cuda")
+    opt = dgtd.runner.FlatAdamW(red, scaler=scaler)
+    data = dgtd.runner.SyntheticRGBD(S, B, device="cuda")
+    before = net.hitnet.backbone.block3[0].mlp.fc1.weight.detach().clone()
+    losses, scales, taken = [], [], []
+    for i in range(6):
+        b = data.batch_at(i % 2)
+        red.zero_grad()
+        loss = net(b["raw"], b["input"], b["label"], b["depth"], mode="loss")["loss"]
+        scaler.scale(loss).backward()
+        red.finish()
+        opt.step()
+        losses.append(loss.item())
+        scales.append(scaler.get_scale())
+        taken.append(opt.steps)
+    print(f"config 5 (512x512, batch 16, fp16): losses {[round(v, 4) for v in losses]}, scales {scales}, steps taken {taken}")
+    assert all(math.isfinite(v) for v in losses), losses
+    assert taken[-1] >= 3 and taken[-1] - taken[-3] == 2, (taken, scales)          # no overflow in the last two steps
+    assert math.isfinite(scales[-1]) and scales[-1] >= 1.0
+    inv = 1.0 / scales[-1]
+    trunks = {"pvt": "hitnet.backbone.block", "convnext": "prompt_encoder.encoder2.stages", "prompt": "prompt_decoder",
+              "diffuser": "propagation_weight_regressor", "decoder": "hitnet.decoder_level", "heads": "hitnet.out_"}
+    norms = {k: 0.0 for k in trunks}
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        assert torch.isfinite(p.grad).all(), n
+        for k, pat in trunks.items():
+            if pat in n:
+                norms[k] += float(p.grad.float().norm()) * inv
+    assert all(v > 0 for v in norms.values()), norms
+    assert not torch.equal(before, net.hitnet.backbone.block3[0].mlp.fc1.weight.detach())
