@@ -13,6 +13,7 @@
 #include <vector>
 #include <c10/hip/HIPStream.h>
 #include <torch/autograd.h>
+#include <torch/csrc/autograd/engine.h>
 #include <torch/library.h>
 
 #include "../../include/dgtd.h"
@@ -83,8 +84,22 @@ inline bool may_defer(AutogradContext* ctx, const char* key) {
   auto u = g_uses.find(leaf.data_ptr());
   return u != g_uses.end() && u->second == 1;
 }
+// SAFETY NET: whoever parks work during a backward pass also queues ONE engine callback that flushes at the end of that pass.  Under the
+// reducer this is where the single flush of a step happens anyway (its own flush calls then find nothing); without it - a step that
+// raised between zero_grad() and finish() leaves deferral switched on, and a later plain backward() would otherwise return with
+// unwritten gradients.
+static std::atomic<bool> g_cb_queued{false};
+inline void queue_final_flush() {
+  if (g_cb_queued.exchange(true)) return;
+  try {
+    torch::autograd::Engine::get_default_engine().queue_callback([] { g_cb_queued.store(false); flush_deferred(); });
+  } catch (...) {            // not inside a backward pass (a node run by hand): the caller flushes
+    g_cb_queued.store(false);
+  }
+}
 inline void park(const Tensor& ws, int nblocks, int ncols, float* outA, int nA, void* outB, dgtd_dtype dtB, int tr_rows = 0, int tr_cols = 0,
                  void* outC = nullptr) {
+  queue_final_flush();
   std::lock_guard<std::mutex> lk(g_pending_mu);
   g_pending.push_back(PendingReduce{dgtd_reduce_entry{ws.data_ptr<float>(), nblocks, ncols, outA, nA, outB, (int32_t)dtB, tr_rows, tr_cols, outC}, ws});
 }
@@ -95,6 +110,7 @@ struct PendingDw { Tensor x, du; void* dw; void* db; int32_t dw_dt; bool has_bia
 static std::vector<PendingDw> g_pending_dw;
 
 inline void park_dw(const Tensor& x, const Tensor& du, Tensor& dw, Tensor& db, bool has_bias, int C, int K) {
+  queue_final_flush();
   std::lock_guard<std::mutex> lk(g_pending_mu);
   g_pending_dw.push_back(PendingDw{x, du, dw.data_ptr(), has_bias ? db.data_ptr() : nullptr, (int32_t)code(dw), has_bias, (int)x.size(0), (int)x.size(1),
                                    (int)x.size(2), C, K});
@@ -128,12 +144,17 @@ static std::map<std::pair<int64_t, int>, Tensor> g_arenas;
 // allocation instead (and, not being in an arena, takes the per-layer weight-gradient path)
 static std::set<std::tuple<int64_t, int, int>> g_slot_used;
 // a captured hipGraph holds raw arena addresses: while pinned, re-allocating an arena is an error (runner/graph.py)
-static std::atomic<bool> g_arena_pinned{false};
-void arena_pin(bool on) { g_arena_pinned.store(on); }
+static std::map<int64_t, int> g_arena_pins;              // group -> number of live graphs referencing it
+void arena_pin(int64_t group, bool on) {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  if (on) ++g_arena_pins[group];
+  else if (g_arena_pins.count(group) && --g_arena_pins[group] <= 0) g_arena_pins.erase(group);
+}
 
 void arena_hint(int64_t group, int64_t idx, int64_t count) { t_hint = Hint{count > 1 ? group : -1, (int)idx, (int)count}; t_roles = Roles{}; }
 void arena_release(int64_t group) {
   std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_arena_pins.erase(group);
   for (auto it = g_arenas.begin(); it != g_arenas.end();) it = it->first.first == group ? g_arenas.erase(it) : std::next(it);
 }
 int64_t arena_bytes() {
@@ -150,7 +171,7 @@ inline Tensor arena_slot(const Hint& h, int role, at::IntArrayRef shape, const a
   if (!g_slot_used.insert({h.group, role, h.idx}).second) return at::empty(shape, opt);
   Tensor& a = g_arenas[{h.group, role}];
   if (!a.defined() || a.sizes() != at::IntArrayRef(full) || a.scalar_type() != c10::typeMetaToScalarType(opt.dtype()) || a.device() != opt.device()) {
-    TORCH_CHECK(!g_arena_pinned.load(), "dgtd: a captured hipGraph references the per-stage arenas; a grad-enabled step with another shape would "
+    TORCH_CHECK(!g_arena_pins.count(h.group), "dgtd: a captured hipGraph references the per-stage arenas; a grad-enabled step with another shape would "
                 "re-allocate them under it (GraphedTrainStep.release() first)");
     a = at::empty(full, opt);
   }
@@ -181,6 +202,7 @@ inline int role_of(const c10::IValue& v, int i) { return (int)v.toIntVector()[3 
 struct PendingGemm { int64_t group; int which, idx; Tensor x, dy; void* dw; int64_t M, N, K; };   // dW [N,K] = dy[M,N]^T x[M,K]
 static std::vector<PendingGemm> g_pending_gemm;
 inline void park_gemm(const Hint& h, int which, const Tensor& x2, const Tensor& dy2, const Tensor& dw) {
+  queue_final_flush();
   std::lock_guard<std::mutex> lk(g_pending_mu);
   g_pending_gemm.push_back(PendingGemm{h.group, which, h.idx, x2, dy2, dw.data_ptr(), dy2.size(0), dy2.size(1), x2.size(1)});
 }
@@ -285,6 +307,7 @@ inline bool conv_dest_exists(const Tensor& w) {
 }
 // backward: park this call; dw / db are set only for the first parked call of the weight.  false: take the immediate path.
 inline bool conv_park(const Tensor& x, const Tensor& dy, const Tensor& mask, const Tensor& w, const ConvKey& k, bool has_b, Tensor& dw, Tensor& db) {
+  queue_final_flush();
   std::lock_guard<std::mutex> lk(g_pending_mu);
   auto seen = g_conv_seen.find(w.data_ptr());
   if (seen == g_conv_seen.end() || seen->second.mixed) return false;
@@ -621,7 +644,7 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
 inline void dwconv_weight_grads(const Tensor& x, const Tensor& du, bool has_bias, int64_t C, int64_t K, Tensor& dw, Tensor& db, bool defer) {
   const int64_t KK = K * K;
   static const bool batch_dw = [] { const char* e = std::getenv("DGTD_DEFER_DWCONV"); return !e || std::atoi(e) != 0; }();
-  if (defer && batch_dw) { park_dw(x, du, dw, db, has_bias, (int)C, (int)K); return; }
+  if (defer && batch_dw && C % 128 == 0) { park_dw(x, du, dw, db, has_bias, (int)C, (int)K); return; }   // the batched kernel walks 128-channel groups
   Tensor ws = at::empty({dgtd_dwconv_bwd_weight_workspace((int)x.size(0), (int)x.size(1), (int)x.size(2), (int)C, (int)K) / 4}, x.options().dtype(at::kFloat));
   int nb = 0;
   check(dgtd_dwconv_bwd_weight_partial(x.data_ptr(), du.data_ptr(), has_bias ? 1 : 0, ws.data_ptr(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
@@ -1160,6 +1183,7 @@ struct PReLUFn : public torch::autograd::Function<PReLUFn> {
     bool share = key && deferring() && g_shared_ok.load(std::memory_order_relaxed);
     if (share) {
       bool have;
+      queue_final_flush();
       { std::lock_guard<std::mutex> lk(g_pending_mu); have = g_prelu_acc.count(key) > 0; }
       if (!have && leaf_has_grad(ctx, "leaf_a")) share = false;       // accumulation: the slope already owns a gradient
     }
@@ -1293,5 +1317,5 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("arena_roles(int out, int grad_a, int grad_b) -> ()", &arena_roles);
   m.def("arena_release(int group) -> ()", &arena_release);
   m.def("arena_bytes() -> int", &arena_bytes);
-  m.def("arena_pin(bool on) -> ()", &arena_pin);
+  m.def("arena_pin(int group, bool on) -> ()", &arena_pin);
 }

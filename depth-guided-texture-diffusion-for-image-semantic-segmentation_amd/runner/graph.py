@@ -71,6 +71,7 @@ class GraphedTrainStep:
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None     # AdamW alone (split mode)
         self.static = None
         self.loss = None
+        self._pinned, self._pinned_groups = False, []
         multi = reducer.world > 1 or reducer._force
         if comm not in ("auto", "fused", "split"):
             raise ValueError(f"comm must be auto, fused or split, got {comm!r}")
@@ -211,18 +212,29 @@ class GraphedTrainStep:
         self._pin_arenas(True)
 
     def _pin_arenas(self, on: bool) -> None:
-        """The captured graph holds raw addresses of the per-stage arenas (csrc_torch/bindings.cpp): while pinned, a request that would
-        re-allocate one (an eager grad-enabled step with another batch shape) raises instead of letting the next replay write freed
-        memory."""
+        """The captured graph holds raw addresses of the per-stage arenas of THIS model (csrc_torch/bindings.cpp): while pinned, a request
+        that would re-allocate one of them (an eager grad-enabled step with another batch shape) raises instead of letting the next
+        replay write freed memory.  Other models' arenas are not affected."""
         from ..ops import _native
         nat = _native.ops()
-        if nat is not None and hasattr(nat, "arena_pin"):
-            nat.arena_pin(on)
+        if nat is None or on == self._pinned:
+            return
+        groups = [g for m in self.net.modules() for g in getattr(m.__dict__.get("_dgtd_arena_token"), "groups", {}).values()]
+        for g in (groups if on else self._pinned_groups):
+            nat.arena_pin(g, on)
+        self._pinned_groups = groups if on else []
+        self._pinned = on
 
     def release(self) -> None:
         """Drop the graphs (and un-pin the arenas they referenced)."""
         self.graph_fb = self.graph_opt = None
         self._pin_arenas(False)
+
+    def __del__(self):
+        try:
+            self._pin_arenas(False)
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ replay
     def __call__(self, batch) -> torch.Tensor:

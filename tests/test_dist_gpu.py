@@ -83,6 +83,7 @@ def _cod_worker(rank, world, port, q, mode):
           'split' = GraphedTrainStep, graph A | bucketed all-reduce | graph B (gloo cannot be captured)."""
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        os.environ["DGTD_GEMM_TUNE"] = "0"     # the library GEMM plan = the heuristic's first answer in every process (see _reference_worker)
         import dgtd
         from oracle import filler
         torch.cuda.set_device(0)
@@ -130,29 +131,38 @@ def _cod_worker(rank, world, port, q, mode):
         raise
 
 
-def _single_process_reference():
-    """world 1, same weights: the gradient of the MEAN of the two ranks' losses = the mean of the per-rank gradients, each rank's
-    batch through its own forward (BatchNorm statistics are per rank in the reference: plain BatchNorm2d, cod.py:362)."""
-    import dgtd
-    from oracle import filler
-    S, B = 64, 2
-    acc, losses = None, []
-    for rank in range(2):
-        net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
-        filler.fill_module(net)
-        net = net.cuda().train()
-        red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
-        x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))
-        red.zero_grad()
-        loss = net(None, x, l, d, mode="loss")["loss"]
-        loss.backward()
-        red.finish()
-        torch.cuda.synchronize()
-        g = {n: p.grad.detach().float().cpu().numpy() / 2 for n, p in net.named_parameters() if p.grad is not None}
-        acc = g if acc is None else {n: acc[n] + g[n] for n in acc}
-        losses.append(loss.item())
-        del net, red
-    return acc, losses
+def _reference_worker(q):
+    """world 1, same weights, own process: the gradient of the MEAN of the two ranks' losses = the mean of the per-rank gradients, each
+    rank's batch through its own forward (BatchNorm statistics are per rank in the reference: plain BatchNorm2d, cod.py:362).
+    Own process + DGTD_GEMM_TUNE=0 like the ranks: the library GEMM plans are otherwise picked by TIMING candidates once per process,
+    two processes can pick differently, and bf16 gradients computed through differently-rounded GEMMs differ by several percent
+    (measured 4-6 % pooled) - the bf16 noise floor of this model, not a property of the reducer."""
+    try:
+        os.environ["DGTD_GEMM_TUNE"] = "0"
+        import dgtd
+        from oracle import filler
+        S, B = 64, 2
+        acc, losses = None, []
+        for rank in range(2):
+            net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+            filler.fill_module(net)
+            net = net.cuda().train()
+            red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
+            x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))
+            red.zero_grad()
+            loss = net(None, x, l, d, mode="loss")["loss"]
+            loss.backward()
+            red.finish()
+            torch.cuda.synchronize()
+            g = {n: p.grad.detach().float().cpu().numpy() / 2 for n, p in net.named_parameters() if p.grad is not None}
+            acc = g if acc is None else {n: acc[n] + g[n] for n in acc}
+            losses.append(loss.item())
+            del net, red
+        q.put(("ref", (acc, losses), None))
+    except Exception:
+        import traceback
+        q.put(("ref", "ERROR: " + traceback.format_exc(), None))
+        raise
 
 
 @pytest.mark.parametrize("mode", ["eager", "split"])
@@ -165,10 +175,11 @@ def test_real_model_two_ranks_one_gpu(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_cod_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    procs.append(ctx.Process(target=_reference_worker, args=(q,)))
     for p in procs:
         p.start()
     res = {}
-    for _ in range(world):
+    for _ in range(world + 1):
         r, payload, _ = q.get(timeout=900)
         assert not isinstance(payload, str), f"rank {r}: {payload}"
         res[r] = payload
@@ -183,7 +194,7 @@ def test_real_model_two_ranks_one_gpu(mode):
     for n in w0:
         assert np.array_equal(w0[n], w1[n]), n                       # replicas in lock-step after two optimizer steps
     assert not np.array_equal(bn0, bn1)                              # BatchNorm statistics are per rank (no SyncBN in the reference)
-    want, lref = _single_process_reference()
+    want, lref = res["ref"]
     assert abs(l0[0] - lref[0]) < 2e-2 * abs(lref[0]) and abs(l1[0] - lref[1]) < 2e-2 * abs(lref[1]), (l0, l1, lref)
     # element-level agreement with the single-process mean gradient: bf16 payload + bf16 atomics noise
     num = den = 0.0
@@ -195,6 +206,11 @@ def test_real_model_two_ranks_one_gpu(mode):
         if m > 1e-12 and e / m > worst[0]:
             worst = (e / m, n)
     rel = (num / den) ** 0.5
+    # the heaviest contributors to the pooled error (name, share of the squared error, own relative L2)
+    contrib = sorted(((float(((g0[n].astype(np.float64) - want[n]) ** 2).sum()) / max(num, 1e-300), n,
+                       (float(((g0[n].astype(np.float64) - want[n]) ** 2).sum()) / max(float((want[n].astype(np.float64) ** 2).sum()), 1e-300)) ** 0.5)
+                      for n in want), reverse=True)[:8]
+    print("top error contributors:", [(n, round(sh, 3), round(r, 4)) for sh, n, r in contrib])
     print(f"[{mode}] 2-rank vs single-process mean gradient: global rel L2 {rel:.4f} (budget 0.03), worst tensor {worst[1]} {worst[0] ** 0.5:.3f}")
     assert rel < 0.03, (rel, worst)
 
