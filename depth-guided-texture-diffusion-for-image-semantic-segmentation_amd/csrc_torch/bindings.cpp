@@ -366,6 +366,7 @@ static void flush_convs(std::vector<PendingConv>& cs, const std::map<const void*
   }
 }
 
+static std::atomic<int64_t> g_flushed{0};
 void flush_deferred() {
   {
     std::vector<PendingConv> convs;
@@ -377,6 +378,7 @@ void flush_deferred() {
       g_prelu_acc.clear();
       g_conv_flip.clear();
     }
+    g_flushed += (int64_t)convs.size();
     if (!convs.empty()) flush_convs(convs, dest);
   }
   std::vector<PendingReduce> todo;
@@ -392,6 +394,7 @@ void flush_deferred() {
     todo.swap(g_pending);
     dws.swap(g_pending_dw);
   }
+  g_flushed += (int64_t)(gemms.size() + todo.size() + dws.size());
   if (todo.empty() && dws.empty()) return;
   std::vector<dgtd_reduce_entry> es;
   es.reserve(todo.size() + dws.size());
@@ -499,6 +502,7 @@ void set_deferred(bool on) {
   g_defer.store(on);
   if (on && prepare_on()) refresh_prepared();
 }
+int64_t flushed_reductions() { return g_flushed.load(); }    // cumulative number of parked entries that flush_deferred() has served
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
   return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size() + g_pending_conv.size());
@@ -1312,6 +1316,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("set_deferred(bool on) -> ()", &set_deferred);
   m.def("flush_deferred() -> ()", &flush_deferred);
   m.def("pending_reductions() -> int", &pending_reductions);
+  m.def("flushed_reductions() -> int", &flushed_reductions);
   m.def("set_shared_deferral(bool on) -> ()", &set_shared_deferral);
   m.def("arena_hint(int group, int idx, int count) -> ()", &arena_hint);
   m.def("arena_roles(int out, int grad_a, int grad_b) -> ()", &arena_roles);

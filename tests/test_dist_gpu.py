@@ -211,8 +211,8 @@ def test_real_model_two_ranks_one_gpu(mode):
                        (float(((g0[n].astype(np.float64) - want[n]) ** 2).sum()) / max(float((want[n].astype(np.float64) ** 2).sum()), 1e-300)) ** 0.5)
                       for n in want), reverse=True)[:8]
     print("top error contributors:", [(n, round(sh, 3), round(r, 4)) for sh, n, r in contrib])
-    print(f"[{mode}] 2-rank vs single-process mean gradient: global rel L2 {rel:.4f} (budget 0.03), worst tensor {worst[1]} {worst[0] ** 0.5:.3f}")
-    assert rel < 0.03, (rel, worst)
+    print(f"[{mode}] 2-rank vs single-process mean gradient: global rel L2 {rel:.4f} (budget 0.005), worst tensor {worst[1]} {worst[0] ** 0.5:.3f}")
+    assert rel < 0.005, (rel, worst)      # measured 0.002 - 0.003: the bf16 payload rounding
 
 
 def test_bench_control_flow_two_ranks_one_gpu(tmp_path):

@@ -354,9 +354,14 @@ def test_deferred_column_reductions_are_bit_identical(dgtd):
             red = dgtd.dist.GradReducer(net, working_dtype=torch.bfloat16)
             red.zero_grad()
             loss = net(None, x, l, d, mode="loss")["loss"]
+            done = nat.flushed_reductions()
             loss.backward()
+            # parked work is flushed by the engine callback at the end of the backward pass (and whatever a hook flushed earlier)
+            assert nat.pending_reductions() == 0
             if defer:
-                assert nat.pending_reductions() > 200          # LayerNorms + Linear biases of both trunks are parked
+                assert nat.flushed_reductions() - done > 200   # LayerNorms + Linear biases of both trunks were parked
+            else:
+                assert nat.flushed_reductions() == done
             red.finish()
             assert nat.pending_reductions() == 0
             grads[defer] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
@@ -399,8 +404,9 @@ def test_batched_weight_gradient_gemms_match_per_layer_path(dgtd):
             for _ in range(2):                                       # second step reuses the arenas
                 red.zero_grad()
                 loss = net(None, x, l, d, mode="loss")["loss"]
+                done = nat.flushed_reductions()
                 loss.backward()
-                parked[batched] = nat.pending_reductions()
+                parked[batched] = nat.flushed_reductions() - done      # everything parked in this backward pass (flushed at its end)
                 red.finish()
             assert nat.pending_reductions() == 0
             grads[batched] = {k: p.grad.float().clone() for k, p in net.named_parameters() if p.grad is not None}
@@ -457,12 +463,12 @@ def _tiny_trunk(dgtd, dtype=torch.bfloat16):
     class Net(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.shared = dgtd.nn.Linear(64, 64)
-            self.norm = dgtd.nn.LayerNorm(64, eps=1e-6)
-            self.dw = dgtd.nn.DWConv(64)
-            self.out = dgtd.nn.Linear(64, 64)
+            self.shared = dgtd.nn.Linear(128, 128)
+            self.norm = dgtd.nn.LayerNorm(128, eps=1e-6)
+            self.dw = dgtd.nn.DWConv(128)            # the depthwise weight-gradient kernels walk 128-channel groups
+            self.out = dgtd.nn.Linear(128, 128)
 
-        def forward(self, x):                       # x [B, 64, 64] tokens of an 8x8 map
+        def forward(self, x):                       # x [B, 64, 128] tokens of an 8x8 map
             h = self.shared(self.shared(x))         # one weight / bias, two call sites
             h = self.dw(self.norm(h), 8, 8, gelu=True)
             return dgtd.ops.linear_residual(h, *dgtd.nn.wb(self.out), x, None)
@@ -477,7 +483,7 @@ def test_deferred_gradients_survive_accumulation(dgtd, case):
     second backward through a retained graph must all give the gradients of the deferral-off run (bit-level: same kernels, immediate
     path) - not sums over uninitialised memory."""
     from dgtd.dist import reducer as R
-    x = torch.randn(2, 64, 64, device="cuda")
+    x = torch.randn(2, 64, 128, device="cuda")
     grads = {}
     for defer in (False, True):
         R.DEFER = defer
