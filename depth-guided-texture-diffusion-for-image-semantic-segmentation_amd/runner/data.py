@@ -60,6 +60,10 @@ def _collate(items, device):
     return out
 
 
+from .registry import export  # noqa: E402
+
+
+@export
 class SyntheticRGBD:
     def __init__(self, size: int, batch: int, rank: int = 0, device="cuda", seed: int = 1234, length: int = 1 << 20):
         self.size, self.batch, self.rank, self.device, self.seed, self.length = size, batch, rank, device, seed, length

@@ -108,11 +108,16 @@ THIRD_PARTY = ("Emeasure", "Fmeasure", "Smeasure", "WeightedFmeasure")   # pure 
 
 
 def build_evaluators(cfg_list, log=print):
+    """``val_evaluator`` entries by ``type``: this module's restated metrics first, then anything ``@export``-ed under that name
+    (runner/registry.py: the reference's twig/metric classes register themselves there when they can be imported)."""
+    from . import registry
     out = []
     for item in cfg_list or []:
         t = item.get("type") if isinstance(item, dict) else str(item)
         if t in EVALUATORS:
             out.append(EVALUATORS[t]())
+        elif t in registry.REGISTRY:
+            out.append(registry.build(item if isinstance(item, dict) else {"type": t}))
         elif t in THIRD_PARTY:
             log(f"val_evaluator {t}: third-party py_sod_metrics arithmetic, not restated here - skipped")
         else:

@@ -101,3 +101,72 @@ def test_half_inputs_compute_in_float32():
     assert out.dtype == torch.float32      # custom_fwd(cast_inputs=torch.float32), ms_deform_attn_func.py:21
     ref = mc.ms_deform_attn(value.bfloat16().float(), shp, loc.bfloat16().float(), attn.bfloat16().float())
     assert torch.allclose(out.cpu(), ref, rtol=1e-2, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ the module-level native binding
+REF_FUNC = "/root/reference/twig/ops/functions/ms_deform_attn_func.py"
+
+
+def test_module_binding_exports_the_reference_callables():
+    """twig/ops/src/vision.cpp:13-16: a module named MultiScaleDeformableAttention with ms_deform_attn_forward / _backward."""
+    import inspect
+    import MultiScaleDeformableAttention as MSDA
+    f, b = inspect.signature(MSDA.ms_deform_attn_forward), inspect.signature(MSDA.ms_deform_attn_backward)
+    assert list(f.parameters)[:6] == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "im2col_step"]
+    assert list(b.parameters)[:7] == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "grad_output", "im2col_step"]
+    with pytest.raises(Exception, match="HIP device|CPU|cpu"):     # no fallback: a CPU tensor is refused loudly
+        v = torch.zeros(1, 4, 1, 4)
+        MSDA.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2), torch.ones(1, 1, 1, 1, 1), 1)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FUNC), reason="the reference tree exists in the build container only")
+def test_reference_function_file_binds_to_the_module_unchanged():
+    """Build container: the reference's own ms_deform_attn_func.py, executed as it is, imports `MultiScaleDeformableAttention` and finds
+    this repository's module - its MSDeformAttnFunction then calls MSDA.ms_deform_attn_forward / _backward of libdgtd.so."""
+    import MultiScaleDeformableAttention as MSDA
+    ns = {"__name__": "ref_ms_deform_attn_func"}
+    exec(compile(open(REF_FUNC).read(), REF_FUNC, "exec"), ns)
+    assert ns["MSDA"] is MSDA
+    fn = ns["MSDeformAttnFunction"]
+    assert issubclass(fn, torch.autograd.Function)
+    # the file's own pure-PyTorch core (ms_deform_attn_func.py:49-71) is what generated tests/golden/msda.npz: one case through it here
+    name = next(iter(mc.CASES))
+    (value, shp, loc, attn, _), y, *_ = _run_oracle(name)
+    got = ns["ms_deform_attn_core_pytorch"](value.detach(), shp, loc.detach(), attn.detach())
+    assert torch.allclose(got, y, rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mc.CASES)[:3])
+def test_reference_shaped_function_over_the_module(G, name):
+    """GPU box (no reference tree): a Function with the body of twig/ops/functions/ms_deform_attn_func.py:19-46 - MSDA.forward in
+    forward(), MSDA.backward's 3-tuple in backward(), `None` for the integer inputs - over the module, against the reference vectors."""
+    import MultiScaleDeformableAttention as MSDA
+    from torch.autograd import Function
+    from torch.autograd.function import once_differentiable
+
+    class RefShaped(Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+            ctx.im2col_step = im2col_step
+            out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, ctx.im2col_step)
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return out
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step)
+            return gv, None, None, gl, ga, None
+
+    N, M, D, Lq, shapes, P = mc.CASES[name]
+    value, shp, loc, attn, grad = mc.case_inputs(name, N, M, D, Lq, shapes, P, torch.float64)
+    v, l_, a = (t.cuda().requires_grad_() for t in (value, loc, attn))
+    out = RefShaped.apply(v, shp.cuda(), _level_start(shp).cuda(), l_, a, 2)
+    hv, hl, ha = torch.autograd.grad(out, (v, l_, a), grad.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), G[f"{name}.out"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(hl.cpu().numpy(), G[f"{name}.grad_loc"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(ha.cpu().numpy(), G[f"{name}.grad_attn"], rtol=1e-8, atol=1e-11)
+    if f"{name}.grad_value" in G:
+        np.testing.assert_allclose(hv.cpu().numpy(), G[f"{name}.grad_value"], rtol=1e-8, atol=1e-11)

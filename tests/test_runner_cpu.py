@@ -195,3 +195,51 @@ def test_cosine_schedule_resumes():
     assert opt2.param_groups[0]["lr"] == lr4
     a.step(); b.step()
     assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+
+def test_export_registry_and_nest_shim():
+    """`from nest import export` (twig/dataset/sod_train.py:2,11; twig/metric/MAE.py:2,8; twig/model/cod.py:34-36) resolves
+    to the runner's registry; exported classes are built from `type:` entries like mmengine does, and exported metrics are visible
+    to val_evaluator."""
+    import sys
+    import dgtd
+    R = dgtd.runner.registry
+    saved = sys.modules.pop("nest", None)
+    try:
+        nest = dgtd.runner.install_nest_shim()
+        from nest import export, register_model
+        assert nest.export is export is R.export
+
+        @export
+        class SOD_TRAIN_LIKE:
+            def __init__(self, data_dir, depth_dir, split, image_size=None):
+                self.args = (data_dir, depth_dir, split, image_size)
+
+        @export
+        class Emeasure:                                   # a metric class the reference exports (twig/metric/Emeasure.py)
+            def __init__(self, prefix=None):
+                self.prefix = prefix
+
+        @export
+        @register_model
+        class tiny_model:
+            def __init__(self, **kw):
+                self.kw = kw
+
+        ds = dgtd.runner.build_exported({"type": "SOD_TRAIN_LIKE", "data_dir": "d", "depth_dir": "dd", "split": "train"})
+        assert ds.args == ("d", "dd", "train", None)
+        assert R.get("tiny_model") is tiny_model and dgtd.runner.config.MODEL_REGISTRY["tiny_model"] is tiny_model
+        assert "SyntheticRGBD" in R.REGISTRY                # the runner's own dataset registers the same way
+        logs = []
+        evs = dgtd.runner.metrics.build_evaluators([{"type": "MAE"}, {"type": "Emeasure", "prefix": "COD"}, {"type": "Smeasure"}], logs.append)
+        assert len(evs) == 2 and isinstance(evs[1], Emeasure) and evs[1].prefix == "COD"      # exported metric wins over "skipped"
+        assert any("Smeasure" in m for m in logs)
+        with pytest.raises(KeyError, match="nothing exported"):
+            R.get("no_such_class")
+    finally:
+        for k in ("SOD_TRAIN_LIKE", "Emeasure", "tiny_model"):
+            R.REGISTRY.pop(k, None)
+        dgtd.runner.config.MODEL_REGISTRY.pop("tiny_model", None)
+        sys.modules.pop("nest", None)
+        if saved is not None:
+            sys.modules["nest"] = saved
