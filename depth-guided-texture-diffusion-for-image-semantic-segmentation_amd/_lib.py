@@ -23,6 +23,13 @@ SIGNATURES = {
     "dgtd_profile_enable": (_i, [_i]),
     "dgtd_profile_dump": (_i64, [C.c_char_p, _i64]),
     "dgtd_profile_empty": (_i, [_vp]),
+    "dgtd_gemm_supported": (_i, [_i, _i, _i, _i]),
+    "dgtd_gemm_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dgtd_gemm_bias_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dgtd_gemm_bias_residual": (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i64, _i, _vp]),
+    "dgtd_gemm_gelu_bwd_workspace": (_i64, [_i, _i]),
+    "dgtd_gemm_gelu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _i, _i, _i, _i, _vp]),
+    "dgtd_transpose_batched": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, _vp]),
     "dgtd_layernorm_fwd": (_i, [_vp, _fp, _fp, _vp, _fp, _fp, _i64, _i, _f, _i, _vp]),
     "dgtd_layernorm_bwd_workspace": (_i64, [_i]),
     "dgtd_layernorm_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i, _i, _vp]),

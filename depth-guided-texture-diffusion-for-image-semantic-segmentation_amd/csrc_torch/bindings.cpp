@@ -66,6 +66,8 @@ static std::atomic<bool> g_defer{false};
 
 inline bool deferring() { return g_defer.load(std::memory_order_relaxed); }
 void flush_deferred();
+static void refresh_transposed();
+inline bool own_gemm_on();
 inline bool is_leaf(const Tensor& t) { return t.defined() && t.requires_grad() && !t.grad_fn(); }
 // forward side: remember the leaf (kept in the node, so its .grad can be inspected in the backward) and count the call
 inline void note_leaf(AutogradContext* ctx, const char* key, const Tensor& t) {
@@ -501,6 +503,7 @@ void set_deferred(bool on) {
   }
   g_defer.store(on);
   if (on && prepare_on()) refresh_prepared();
+  if (on && own_gemm_on()) refresh_transposed();
 }
 int64_t flushed_reductions() { return g_flushed.load(); }    // cumulative number of parked entries that flush_deferred() has served
 int64_t pending_reductions() {
@@ -811,10 +814,79 @@ Tensor colsum(const Tensor& x2, at::ScalarType out_dt, bool defer) {
   return out;
 }
 
+// ------------------------------------------------------------------------------------------------ the package's own MFMA GEMM (csrc/gemm.hip)
+// DGTD_OWN_GEMM=0 keeps every Linear on the library GEMM (A/B switch).  Shapes outside the kernel (M % 128, N % 64, K % 64) always do.
+inline bool own_gemm_on() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_OWN_GEMM"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+inline bool aligned16(const Tensor& t) { return ((uintptr_t)t.data_ptr() & 15) == 0; }
+inline bool own_ok(at::ScalarType dt, int64_t M, int64_t N, int64_t K) {
+  return own_gemm_on() && is16(dt) && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) &&
+         dgtd_gemm_supported((int)M, (int)N, (int)K, dt == at::kHalf ? DGTD_F16 : DGTD_BF16);
+}
+// TRANSPOSED WEIGHT COPIES: the input-gradient GEMM dX = dY W runs through the same K-contiguous kernel on W^T.  Weights change only
+// between steps, so under the reducer a weight transposes itself once (first backward) into a PERSISTENT buffer and registers it;
+// from then on set_deferred(true) - the start of every step - refreshes all registered copies in one launch per 64 weights.  Entries
+// die with the weight's storage.  Outside zero_grad() .. finish() the copy is made on the fly.
+struct PreparedWt { c10::weak_intrusive_ptr<c10::StorageImpl> wstore; const void* w; Tensor wt; int rows, cols; at::ScalarType dt; };
+static std::map<const void*, PreparedWt> g_prepared_wt;
+static void refresh_transposed() {
+  std::map<int, std::vector<PreparedWt*>> by_dt;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    for (auto it = g_prepared_wt.begin(); it != g_prepared_wt.end();) {
+      if (it->second.wstore.expired()) it = g_prepared_wt.erase(it);
+      else { by_dt[(int)it->second.dt].push_back(&it->second); ++it; }
+    }
+  }
+  for (auto& kv : by_dt) {
+    std::vector<const void*> src;
+    std::vector<void*> dst;
+    std::vector<int> rows, cols;
+    for (auto* p : kv.second) { src.push_back(p->w); dst.push_back(p->wt.data_ptr()); rows.push_back(p->rows); cols.push_back(p->cols); }
+    check(dgtd_transpose_batched(src.data(), dst.data(), rows.data(), cols.data(), (int)src.size(), kv.first == (int)at::kHalf ? DGTD_F16 : DGTD_BF16,
+                                 stream()), "dgtd_transpose_batched");
+  }
+}
+inline Tensor transposed_weight(const Tensor& wc) {                  // [N,K] contiguous 16-bit -> [K,N]
+  const bool use = deferring() && wc.has_storage();
+  if (use) {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    auto it = g_prepared_wt.find(wc.data_ptr());
+    if (it != g_prepared_wt.end()) {
+      PreparedWt& p = it->second;
+      auto st = p.wstore.lock();
+      if (st && st.get() == wc.storage().unsafeGetStorageImpl() && p.rows == wc.size(0) && p.cols == wc.size(1) && p.dt == wc.scalar_type() &&
+          p.wt.device() == wc.device())
+        return p.wt;
+      g_prepared_wt.erase(it);
+    }
+  }
+  Tensor wt = at::empty({wc.size(1), wc.size(0)}, wc.options());
+  const void* src = wc.data_ptr();
+  void* dst = wt.data_ptr();
+  const int rows = (int)wc.size(0), cols = (int)wc.size(1);
+  check(dgtd_transpose_batched(&src, &dst, &rows, &cols, 1, code(wc), stream()), "dgtd_transpose_batched");
+  if (use) {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    g_prepared_wt.emplace(wc.data_ptr(),
+                          PreparedWt{c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(wc.storage().unsafeGetStorageImpl())),
+                                     wc.data_ptr(), wt, rows, cols, wc.scalar_type()});
+  }
+  return wt;
+}
+
 // GEMM helpers shared by the Linear nodes: bf16 / fp16 go to hipBLASLt with cached plans (gemm.h), anything else to ATen.
 inline Tensor gemm_fwd(const Tensor& x2, const Tensor& wc, const Tensor& bc, Tensor o2 = Tensor()) {   // [M,K] x [N,K]^T (+ bias[N]) -> [M,N]
   const int64_t M = x2.size(0), K = x2.size(1), N = wc.size(0);
   if (!o2.defined()) o2 = at::empty({M, N}, x2.options());
+  if (own_ok(x2.scalar_type(), M, N, K) && x2.is_contiguous() && wc.is_contiguous() && o2.is_contiguous() && aligned16(x2) && aligned16(wc) &&
+      aligned16(o2) && (!bc.defined() || aligned16(bc))) {
+    check(dgtd_gemm_bias(x2.data_ptr(), wc.data_ptr(), bc.defined() ? bc.data_ptr() : nullptr, o2.data_ptr(), (int)M, (int)N, (int)K, code(x2), stream()),
+          "dgtd_gemm_bias");
+    return o2;
+  }
   const bool direct = is16(x2.scalar_type()) && M > 0 && x2.is_contiguous() && wc.is_contiguous() &&
                       dgemm::matmul_16(x2.scalar_type(), x2.data_ptr(), wc.data_ptr(), o2.data_ptr(), bc.defined() ? bc.data_ptr() : nullptr, M, N, K, false,
                                          true, 1, 0, 0, 0, x2.options(), (hipStream_t)stream());
@@ -827,6 +899,11 @@ inline Tensor gemm_fwd(const Tensor& x2, const Tensor& wc, const Tensor& bc, Ten
 inline Tensor gemm_dx(const Tensor& dy2, const Tensor& wc) {                              // [M,N] x [N,K] -> [M,K]
   const int64_t M = dy2.size(0), N = wc.size(0), K = wc.size(1);
   Tensor dx2 = at::empty({M, K}, dy2.options());
+  if (own_ok(dy2.scalar_type(), M, K, N) && dy2.is_contiguous() && wc.is_contiguous() && aligned16(dy2) && aligned16(wc)) {
+    Tensor wt = transposed_weight(wc);                      // [K,N]: contiguous in the reduction dim
+    check(dgtd_gemm_bias(dy2.data_ptr(), wt.data_ptr(), nullptr, dx2.data_ptr(), (int)M, (int)K, (int)N, code(dy2), stream()), "dgtd_gemm_bias (input gradient)");
+    return dx2;
+  }
   const bool bf = is16(dy2.scalar_type()) && wc.is_contiguous() && M > 0;
   if (!(bf && dgemm::matmul_16(dy2.scalar_type(), dy2.data_ptr(), wc.data_ptr(), dx2.data_ptr(), nullptr, M, K, N, false, false, 1, 0, 0, 0, dy2.options(),
                                  (hipStream_t)stream())))
@@ -928,7 +1005,9 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor x2 = as_rows(x, dt);
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
     Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
-    Tensor pre = gemm_fwd(x2, wc, bc);
+    const int64_t Mg = x2.size(0), Kg = x2.size(1), Ng = wc.size(0);
+    const bool fused = own_ok(dt, Mg, Ng, Kg) && x2.is_contiguous() && wc.is_contiguous() && aligned16(x2) && aligned16(wc) && aligned16(bc);
+    Tensor pre = fused ? at::empty({Mg, Ng}, x2.options()) : gemm_fwd(x2, wc, bc);
     // under an arena hint (a block of a run of identical blocks): the GELU output = pwconv2's input goes to slot idx of the stage arena,
     // and the backward defers dW when this node's own input already sits in its arena (written there by the hinted LayerNorm)
     const Hint hint = t_hint;
@@ -937,7 +1016,11 @@ struct LinearGeluFn : public torch::autograd::Function<LinearGeluFn> {
     Tensor h = (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, with_last(x, w.size(0)), pre.options())
                                      : at::empty(with_last(x, w.size(0)), pre.options());
     Tensor h2 = h.view({-1, w.size(0)});
-    at::gelu_out(h2, pre);
+    if (fused)       // ONE launch: GEMM, bias, pre-activation and GELU(pre) written from the same accumulators (csrc/gemm.hip)
+      check(dgtd_gemm_bias_gelu(x2.data_ptr(), wc.data_ptr(), bc.data_ptr(), pre.data_ptr(), h2.data_ptr(), (int)Mg, (int)Ng, (int)Kg, code(x2), stream()),
+            "dgtd_gemm_bias_gelu");
+    else
+      at::gelu_out(h2, pre);
     const int xr = ar ? find_role(hint, ROLE_X, x2) : -1;
     ctx->saved_data["hint"] = hint_iv(xr >= 0 ? hint : Hint{}, xr);
     note_leaf(ctx, "leaf_w", w);
@@ -996,12 +1079,23 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     Tensor wc = w.scalar_type() == dt ? w : w.to(dt);
     Tensor bc = b.scalar_type() == dt ? b.contiguous() : b.to(dt);
     Tensor x = (x_.scalar_type() == dt ? x_ : x_.to(dt)).contiguous();
-    Tensor y = gemm_fwd(h2, wc, bc);
     const int64_t B = x.size(0), C = x.size(-1), rows = x.numel() / C;
     Tensor s = has_s ? f32(*s_) : Tensor(), g32 = has_g ? f32(*gamma_) : Tensor();
     Tensor out = at::empty_like(x);
-    check(dgtd_scale_residual_fwd(x.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
-                                  out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
+    const int64_t Kg = h2.size(1);
+    const bool fused = own_ok(dt, rows, C, Kg) && h2.size(0) == rows && wc.size(0) == C && h2.is_contiguous() && wc.is_contiguous() && aligned16(h2) &&
+                       aligned16(wc) && aligned16(bc) && aligned16(x);
+    Tensor y;
+    if (fused) {     // ONE launch: GEMM + bias + x + s*gamma*y; y itself is kept only where the backward reads it (the layer-scale gradient)
+      y = has_g ? at::empty({rows, C}, x.options()) : at::empty({0}, x.options());
+      check(dgtd_gemm_bias_residual(h2.data_ptr(), wc.data_ptr(), bc.data_ptr(), x.data_ptr(), has_s ? s.data_ptr<float>() : nullptr,
+                                    has_g ? g32.data_ptr<float>() : nullptr, has_g ? y.data_ptr() : nullptr, out.data_ptr(), (int)rows, (int)C, (int)Kg,
+                                    rows / B, code(x), stream()), "dgtd_gemm_bias_residual");
+    } else {
+      y = gemm_fwd(h2, wc, bc);
+      check(dgtd_scale_residual_fwd(x.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                    out.data_ptr(), rows, (int)C, rows / B, code(x), stream()), "dgtd_scale_residual_fwd");
+    }
     ctx->save_for_backward({h2, wc, y, s, g32});
     const Hint hint = t_hint;
     const int xr = (hinted(hint, dt) && w.scalar_type() == dt) ? find_role(hint, ROLE_X, h2) : -1;
@@ -1021,26 +1115,27 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
     const bool has_s = m[0], has_g = m[1], need_dh = m[5];
     const auto w_dt = (at::ScalarType)m[2], b_dt = (at::ScalarType)m[3], g_dt = (at::ScalarType)m[4];
     Tensor g = gr[0].contiguous();
-    if (g.scalar_type() != y.scalar_type()) g = g.to(y.scalar_type());
-    const int64_t rows = y.size(0), C = y.size(1), B = m[6];
+    if (g.scalar_type() != h2.scalar_type()) g = g.to(h2.scalar_type());
+    // y (the Linear's own output) may be an empty placeholder: the fused forward keeps it only for the layer-scale gradient
+    const int64_t rows = h2.size(0), C = wc.size(0), B = m[6];
     const Hint hint = hint_of(ctx->saved_data["hint"]);
     const int xr = role_of(ctx->saved_data["hint"], 0);
     const bool ar = hint.group >= 0 && deferring();
-    Tensor dy = ar ? arena_slot(hint, ROLE_DY + xr, y.sizes(), y.options()) : at::empty_like(y);
-    Tensor db = at::empty({C}, y.options().dtype(b_dt));
-    Tensor dgamma = has_g ? at::empty({C}, y.options().dtype(at::kFloat)) : Tensor();
-    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, y.options().dtype(at::kFloat));
+    Tensor dy = ar ? arena_slot(hint, ROLE_DY + xr, {rows, C}, h2.options()) : at::empty({rows, C}, h2.options());
+    Tensor db = at::empty({C}, h2.options().dtype(b_dt));
+    Tensor dgamma = has_g ? at::empty({C}, h2.options().dtype(at::kFloat)) : Tensor();
+    Tensor ws = at::empty({dgtd_colsum2_workspace((int)C) / 4}, h2.options().dtype(at::kFloat));
     // the layer-scale gradient is deferred only when it needs no dtype conversion afterwards (gamma is an fp32 parameter on this path)
     if ((!has_g || (g_dt == at::kFloat && may_defer(ctx, "leaf_g"))) && may_defer(ctx, "leaf_b")) {
       int nb = 0;
       check(dgtd_scale_residual_bias_bwd_partial(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr,
                                                  has_g ? g32.data_ptr<float>() : nullptr, dy.data_ptr(), ws.data_ptr(), rows, (int)C, rows / B,
-                                                 code(y), &nb, stream()), "dgtd_scale_residual_bias_bwd_partial");
+                                                 code(h2), &nb, stream()), "dgtd_scale_residual_bias_bwd_partial");
       park(ws, nb, 2 * (int)C, has_g ? dgamma.data_ptr<float>() : nullptr, (int)C, db.data_ptr(), code(db));
     } else {
       check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
                                          dy.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, db.data_ptr(), code(db), ws.data_ptr(), rows,
-                                         (int)C, rows / B, code(y), stream()), "dgtd_scale_residual_bias_bwd");
+                                         (int)C, rows / B, code(h2), stream()), "dgtd_scale_residual_bias_bwd");
     }
     Tensor dh;
     if (need_dh) dh = gemm_dx(dy, wc).view(ctx->saved_data["hshape"].toIntVector());
@@ -1057,6 +1152,107 @@ struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
   }
 };
 
+
+// out = x + s[b] * gamma[c] * (gelu(v W1^T + b1) W2^T + b2) as ONE node: the whole pointwise half of a convnext_Block (cod.py:1097-1116)
+// on the package's own GEMM.  Forward = two launches (GEMM + bias + GELU writing pre and h; GEMM + bias + layer scale + DropPath +
+// residual).  Backward = scale-residual backward (dy2, dgamma, db2 partials), then the input gradient of pwconv2 taken THROUGH the GELU
+// inside its GEMM's epilogue (dpre = (dy2 W2) * gelu'(pre), bias-gradient partials of pwconv1 from the same tile), then the input
+// gradient of pwconv1: no pass over the [tokens, 4C] hidden tensor outside a GEMM.  Weight gradients: deferred batched GEMMs (arenas).
+struct MlpResidualFn : public torch::autograd::Function<MlpResidualFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& v, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, const Tensor& x_,
+                        const c10::optional<Tensor>& s_, const c10::optional<Tensor>& gamma_, int64_t dt_code) {
+    const auto dt = from_code(dt_code);
+    const bool has_s = s_.has_value() && s_->defined(), has_g = gamma_.has_value() && gamma_->defined();
+    Tensor v2 = as_rows(v, dt);
+    Tensor wc1 = (w1.scalar_type() == dt ? w1 : w1.to(dt)).contiguous(), wc2 = (w2.scalar_type() == dt ? w2 : w2.to(dt)).contiguous();
+    Tensor bc1 = b1.scalar_type() == dt ? b1.contiguous() : b1.to(dt), bc2 = b2.scalar_type() == dt ? b2.contiguous() : b2.to(dt);
+    Tensor x = (x_.scalar_type() == dt ? x_ : x_.to(dt)).contiguous();
+    const int64_t M = v2.size(0), C = v2.size(1), H4 = wc1.size(0), B = x.size(0);
+    TORCH_CHECK(own_ok(dt, M, H4, C) && own_ok(dt, M, C, H4) && wc2.size(0) == C && wc2.size(1) == H4 && x.numel() == M * C && aligned16(v2) &&
+                aligned16(wc1) && aligned16(wc2) && aligned16(bc1) && aligned16(bc2) && aligned16(x),
+                "dgtd mlp_residual: shapes outside the package's GEMM (check dgtd.gemm_ok first)");
+    const Hint hint = t_hint;
+    const int out_role = take_out_role();
+    const bool ar = hinted(hint, dt) && w1.scalar_type() == dt && w2.scalar_type() == dt;
+    Tensor pre = at::empty({M, H4}, v2.options());
+    Tensor h = (ar && out_role >= 0) ? arena_slot(hint, ROLE_X + out_role, {M, H4}, v2.options()) : at::empty({M, H4}, v2.options());
+    check(dgtd_gemm_bias_gelu(v2.data_ptr(), wc1.data_ptr(), bc1.data_ptr(), pre.data_ptr(), h.data_ptr(), (int)M, (int)H4, (int)C, code(v2), stream()),
+          "dgtd_gemm_bias_gelu");
+    Tensor s = has_s ? f32(*s_) : Tensor(), g32 = has_g ? f32(*gamma_) : Tensor();
+    Tensor y = has_g ? at::empty({M, C}, v2.options()) : at::empty({0}, v2.options());
+    Tensor out = at::empty_like(x);
+    check(dgtd_gemm_bias_residual(h.data_ptr(), wc2.data_ptr(), bc2.data_ptr(), x.data_ptr(), has_s ? s.data_ptr<float>() : nullptr,
+                                  has_g ? g32.data_ptr<float>() : nullptr, has_g ? y.data_ptr() : nullptr, out.data_ptr(), (int)M, (int)C, (int)H4, M / B,
+                                  code(v2), stream()), "dgtd_gemm_bias_residual");
+    const int r1 = ar ? find_role(hint, ROLE_X, v2) : -1, r2 = ar ? find_role(hint, ROLE_X, h) : -1;
+    ctx->saved_data["hint"] = hint_iv((r1 >= 0 && r2 >= 0) ? hint : Hint{}, r1, r2);
+    note_leaf(ctx, "leaf_w1", w1); note_leaf(ctx, "leaf_b1", b1); note_leaf(ctx, "leaf_w2", w2); note_leaf(ctx, "leaf_b2", b2);
+    if (has_g) note_leaf(ctx, "leaf_g", *gamma_);
+    ctx->save_for_backward({v2, wc1, wc2, pre, h, y, s, g32});
+    ctx->saved_data["vshape"] = v.sizes().vec();
+    ctx->saved_data["meta"] = std::vector<int64_t>{has_s, has_g, st_id(w1), st_id(b1), st_id(w2), st_id(b2), has_g ? st_id(*gamma_) : (int64_t)at::kFloat,
+                                                   v.requires_grad(), B};
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &v2 = saved[0], &wc1 = saved[1], &wc2 = saved[2], &pre = saved[3], &h = saved[4], &y = saved[5], &s = saved[6], &g32 = saved[7];
+    const auto m = ctx->saved_data["meta"].toIntVector();
+    const bool has_s = m[0], has_g = m[1], need_dv = m[7];
+    const auto w1_dt = (at::ScalarType)m[2], b1_dt = (at::ScalarType)m[3], w2_dt = (at::ScalarType)m[4], b2_dt = (at::ScalarType)m[5], g_dt = (at::ScalarType)m[6];
+    const int64_t M = v2.size(0), C = v2.size(1), H4 = wc1.size(0), B = m[8];
+    Tensor g = gr[0].contiguous();
+    if (g.scalar_type() != v2.scalar_type()) g = g.to(v2.scalar_type());
+    const Hint hint = hint_of(ctx->saved_data["hint"]);
+    const int r1 = role_of(ctx->saved_data["hint"], 0), r2 = role_of(ctx->saved_data["hint"], 1);
+    const bool ar = hint.group >= 0 && deferring();
+    // (1) through the residual epilogue: dy2 = s * gamma * g, dgamma = sum g * s * y, db2 = sum dy2
+    Tensor dy2 = ar ? arena_slot(hint, ROLE_DY + r2, {M, C}, v2.options()) : at::empty({M, C}, v2.options());
+    Tensor db2 = at::empty({C}, v2.options().dtype(b2_dt));
+    Tensor dgamma = has_g ? at::empty({C}, v2.options().dtype(at::kFloat)) : Tensor();
+    Tensor ws2 = at::empty({dgtd_colsum2_workspace((int)C) / 4}, v2.options().dtype(at::kFloat));
+    if ((!has_g || (g_dt == at::kFloat && may_defer(ctx, "leaf_g"))) && may_defer(ctx, "leaf_b2")) {
+      int nb = 0;
+      check(dgtd_scale_residual_bias_bwd_partial(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                                 dy2.data_ptr(), ws2.data_ptr(), M, (int)C, M / B, code(v2), &nb, stream()),
+            "dgtd_scale_residual_bias_bwd_partial");
+      park(ws2, nb, 2 * (int)C, has_g ? dgamma.data_ptr<float>() : nullptr, (int)C, db2.data_ptr(), code(db2));
+    } else {
+      check(dgtd_scale_residual_bias_bwd(g.data_ptr(), y.data_ptr(), has_s ? s.data_ptr<float>() : nullptr, has_g ? g32.data_ptr<float>() : nullptr,
+                                         dy2.data_ptr(), has_g ? dgamma.data_ptr<float>() : nullptr, db2.data_ptr(), code(db2), ws2.data_ptr(), M, (int)C,
+                                         M / B, code(v2), stream()), "dgtd_scale_residual_bias_bwd");
+    }
+    // (2) input gradient of pwconv2 through the GELU, bias-gradient partials of pwconv1 from the same tiles
+    Tensor dpre = ar ? arena_slot(hint, ROLE_DY + r1, {M, H4}, v2.options()) : at::empty({M, H4}, v2.options());
+    Tensor db1 = at::empty({H4}, v2.options().dtype(b1_dt));
+    Tensor ws1 = at::empty({dgtd_gemm_gelu_bwd_workspace((int)M, (int)H4) / 4}, v2.options().dtype(at::kFloat));
+    int nb1 = 0;
+    check(dgtd_gemm_gelu_bwd(dy2.data_ptr(), transposed_weight(wc2).data_ptr(), pre.data_ptr(), dpre.data_ptr(), ws1.data_ptr(), &nb1, (int)M, (int)H4,
+                             (int)C, code(v2), stream()), "dgtd_gemm_gelu_bwd");
+    if (may_defer(ctx, "leaf_b1")) {
+      park(ws1, nb1, (int)H4, nullptr, 0, db1.data_ptr(), code(db1));
+    } else {
+      const dgtd_reduce_entry e{ws1.data_ptr<float>(), nb1, (int32_t)H4, nullptr, 0, db1.data_ptr(), (int32_t)code(db1), 0, 0, nullptr};
+      check(dgtd_multi_reduce(&e, 1, stream()), "dgtd_multi_reduce");
+    }
+    // (3) input gradient of pwconv1
+    Tensor dv;
+    if (need_dv) {
+      dv = at::empty({M, C}, v2.options());
+      check(dgtd_gemm_bias(dpre.data_ptr(), transposed_weight(wc1).data_ptr(), nullptr, dv.data_ptr(), (int)M, (int)C, (int)H4, code(v2), stream()),
+            "dgtd_gemm_bias (input gradient)");
+      dv = dv.view(ctx->saved_data["vshape"].toIntVector());
+    }
+    // (4) weight gradients: parked for the batched GEMMs of the deferred phase, or per layer
+    Tensor dw1, dw2;
+    if (ar && may_defer(ctx, "leaf_w2")) { dw2 = arena_slot(hint, ROLE_DW + r2, wc2.sizes(), wc2.options()); park_gemm(hint, r2, h, dy2, dw2); }
+    else { dw2 = gemm_dw(dy2, h); if (dw2.scalar_type() != w2_dt) dw2 = dw2.to(w2_dt); }
+    if (ar && may_defer(ctx, "leaf_w1")) { dw1 = arena_slot(hint, ROLE_DW + r1, wc1.sizes(), wc1.options()); park_gemm(hint, r1, v2, dpre, dw1); }
+    else { dw1 = gemm_dw(dpre, v2); if (dw1.scalar_type() != w1_dt) dw1 = dw1.to(w1_dt); }
+    if (has_g && g_dt != at::kFloat) dgamma = dgamma.to(g_dt);
+    return {dv, dw1, db1, dw2, db2, g, undefined(), dgamma, undefined()};
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ dense conv3x3 (NHWC bf16 MFMA)
 // raw form: x [Z|1,B,H,W,Ci], w [Z,Co,3,3,Ci], b [Z,Co]? -> y [Z,B,H,W,Co]
@@ -1290,6 +1486,11 @@ Tensor linear_residual(const Tensor& h, const Tensor& w, const Tensor& b, const 
                        const c10::optional<Tensor>& gamma, int64_t dt_code) {
   return LinearResidualFn::apply(h, w, b, x, s, gamma, dt_code);
 }
+Tensor mlp_residual(const Tensor& v, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, const Tensor& x,
+                    const c10::optional<Tensor>& s, const c10::optional<Tensor>& gamma, int64_t dt_code) {
+  return MlpResidualFn::apply(v, w1, b1, w2, b2, x, s, gamma, dt_code);
+}
+bool gemm_ok(int64_t M, int64_t N, int64_t K, int64_t dt_code) { return own_ok(from_code(dt_code), M, N, K); }
 Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3Fn::apply(x, w, b, relu); }
 Tensor conv3x3_cl(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3ClFn::apply(x, w, b, relu); }
 Tensor prelu(const Tensor& x, const Tensor& a) { return PReLUFn::apply(x, a); }
@@ -1308,6 +1509,8 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("linear(Tensor x, Tensor weight, Tensor? bias, int dtype_code) -> Tensor", &linear);
   m.def("linear_gelu(Tensor x, Tensor weight, Tensor bias, int dtype_code) -> Tensor", &linear_gelu);
   m.def("linear_residual(Tensor h, Tensor weight, Tensor bias, Tensor x, Tensor? s, Tensor? gamma, int dtype_code) -> Tensor", &linear_residual);
+  m.def("mlp_residual(Tensor v, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor x, Tensor? s, Tensor? gamma, int dtype_code) -> Tensor", &mlp_residual);
+  m.def("gemm_ok(int M, int N, int K, int dtype_code) -> bool", &gemm_ok);
   m.def("conv3x3(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3);
   m.def("conv3x3_cl(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3_cl);
   m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);

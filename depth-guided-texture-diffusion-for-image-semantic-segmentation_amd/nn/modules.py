@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -282,6 +282,8 @@ class convnext_Block(nn.Module):
             run.roles(out=0)                      # LayerNorm output = input of pwconv1 (deferred Linear 0 of the block)
             y = self.norm(y)
             run.roles(out=1)                      # GELU output = input of pwconv2 (deferred Linear 1)
+            if _USE["mlp_fused"]:                 # both Linears + GELU + layer scale + DropPath + residual: one node on the package's own GEMM
+                return ops.mlp_residual(y, *wb(self.pwconv1), *wb(self.pwconv2), xs, s, self.gamma)
             h = ops.linear_gelu(y, *wb(self.pwconv1))
             return ops.linear_residual(h, *wb(self.pwconv2), xs, s, self.gamma)
         y = ops.dwconv_nhwc(x, *wb(self.dwconv))

@@ -7,7 +7,7 @@ from .layernorm import layer_norm, layer_norm_fork  # noqa: F401
 from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401
 from .dwconv import dwconv_fork, dwconv_nhwc  # noqa: F401
-from .elementwise import colsum, linear, linear_gelu, linear_residual, scale_residual  # noqa: F401
+from .elementwise import colsum, linear, linear_gelu, linear_residual, mlp_residual, scale_residual  # noqa: F401
 from . import conv3x3 as conv3x3_ops  # noqa: F401
 from .conv3x3 import conv3x3, conv3x3_stack  # noqa: F401
 from .hitnet import bilinear_resize, ca_gate, cat_channels, prelu, stack, unstack  # noqa: F401

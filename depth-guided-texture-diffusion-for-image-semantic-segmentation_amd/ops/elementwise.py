@@ -178,3 +178,16 @@ def linear_residual(h, w, b, x, s=None, gamma=None):
         with torch.autocast("cuda", enabled=False):
             return nat.linear_residual(h, w, b, x, s, gamma, code)
     return scale_residual(x, linear(h, w, b), s, gamma)
+
+
+def mlp_residual(v, w1, b1, w2, b2, x, s=None, gamma=None):
+    """x + s[b] * gamma[c] * (gelu(v W1^T + b1) W2^T + b2): the pointwise half of a convnext_Block (cod.py:1097-1116) as ONE autograd
+    node on the package's own MFMA GEMM (csrc/gemm.hip): bias + GELU and bias + layer scale + DropPath + residual are GEMM epilogues,
+    and in the backward GELU' and both bias gradients are too.  Falls back to linear_gelu + linear_residual for shapes outside the kernel."""
+    nat, code = _native_dt(v)
+    if nat is not None and b1 is not None and b2 is not None and code != L.F32:
+        M, C, H4 = v.numel() // v.shape[-1], v.shape[-1], w1.shape[0]
+        if w1.dtype == v.dtype == w2.dtype and nat.gemm_ok(M, H4, C, code) and nat.gemm_ok(M, C, H4, code):
+            with torch.autocast("cuda", enabled=False):
+                return nat.mlp_residual(v, w1, b1, w2, b2, x, s, gamma, code)
+    return linear_residual(linear_gelu(v, w1, b1), w2, b2, x, s, gamma)

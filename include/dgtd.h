@@ -172,6 +172,33 @@ int dgtd_colsum_partial(const void* x, void* workspace, int64_t rows, int C, dgt
 int dgtd_colsum(const void* x, void* out, dgtd_dtype out_dt, void* workspace, int64_t rows, int C, dgtd_dtype dt,
                 dgtd_stream st);
 
+/* ---- The Linear layers as a hand-written MFMA GEMM with this model's epilogues (bf16 / fp16; csrc/gemm.hip) ----------------------
+ * D[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous (nn.Linear's x [tokens, in] and weight [out, in]), fp32 accumulation,
+ * all epilogue arithmetic in fp32 with one rounding per output.  Replaces the library GEMM plus the elementwise passes around it at
+ * twig/model/cod.py:900-921 (q / kv / proj), :852-859 (fc1 / fc2), :1097-1099 + :1112-1116 (pwconv1 + GELU, pwconv2 + gamma + DropPath
+ * + residual).  Shapes: M % 128 == 0, N % 64 == 0, K % 64 == 0 (dgtd_gemm_supported); everything 16-byte aligned.
+ *   gemm_bias:          d = a b^T + bias                                   (bias [N] in dt or NULL)
+ *   gemm_bias_gelu:     pre = a b^T + bias (stored when pre != NULL: the backward needs it), h = gelu_erf(pre)
+ *   gemm_bias_residual: y = a b^T + bias (stored when y != NULL: the layer-scale gradient needs it),
+ *                       out = x + scale[row / rows_per_sample] * gamma[col] * y   (scale / gamma fp32 or NULL)
+ *   gemm_gelu_bwd:      dpre = (dy w_t^T) * gelu_erf'(pre): the input gradient of the Linear that FOLLOWS a GELU taken through the GELU,
+ *                       w_t = that Linear's weight TRANSPOSED ([in, out]: K-contiguous in the reduction dim); colsum_ws (bytes:
+ *                       dgtd_gemm_gelu_bwd_workspace) receives [*nblocks][N] fp32 column partials of dpre = first stage of the bias
+ *                       gradient of the Linear in front of the GELU (second stage: dgtd_multi_reduce); NULL: no partials.
+ * An input gradient dX[M,K] = dY[M,N] . W[N,K] is gemm_bias(dy, w_t, NULL, dx, M, K, N): the same kernel on the transposed weight copy;
+ * dgtd_transpose_batched refreshes those copies (dst[i] [cols][rows] = src[i] [rows][cols]^T) for a whole model in one launch.      */
+int dgtd_gemm_supported(int M, int N, int K, dgtd_dtype dt);
+int dgtd_gemm_bias(const void* a, const void* b, const void* bias, void* d, int M, int N, int K, dgtd_dtype dt, dgtd_stream s);
+int dgtd_gemm_bias_gelu(const void* a, const void* b, const void* bias, void* pre, void* h, int M, int N, int K, dgtd_dtype dt,
+                        dgtd_stream s);
+int dgtd_gemm_bias_residual(const void* a, const void* b, const void* bias, const void* x, const float* scale, const float* gamma,
+                            void* y, void* out, int M, int N, int K, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream s);
+int64_t dgtd_gemm_gelu_bwd_workspace(int M, int N);
+int dgtd_gemm_gelu_bwd(const void* dy, const void* w_t, const void* pre, void* dpre, void* colsum_ws, int* nblocks, int M, int N, int K,
+                       dgtd_dtype dt, dgtd_stream s);
+int dgtd_transpose_batched(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, dgtd_dtype dt,
+                           dgtd_stream s);
+
 /* ---- Fused structure loss of the five deep-supervision heads (fp32) -------------------------------
  * loss = sum_k mix[k] * cal_loss(bilinear_x(S/hs)(lo[k]), label): twig/model/cod.py:76-85 (weighted BCE + weighted IoU with
  * weit = 1 + 5|avgpool31(gt) - gt|), :137-142 (mix = 0, .2, .4, .6 for P1[0..3], 1 for P2) and the x8 align_corners=False

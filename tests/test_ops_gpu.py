@@ -765,3 +765,100 @@ def test_ssim_value_vs_oracle(dgtd, B, S):
     want = cod_cpu.ssim_value(e, img).item()
     got = dgtd.ops.ssim_value(x_hp.cuda(), img.cuda()).item()
     assert abs(got - want) < 2e-6, (got, want)
+
+
+# ---------------------------------------------------------------------------------------------- the package's own MFMA GEMM (csrc/gemm.hip)
+GEMM_SHAPES = [(128, 64, 64), (256, 128, 128), (1024, 512, 128), (8192, 2048, 512), (8192, 512, 2048), (2048, 320, 1280), (2048, 1280, 320),
+               (32768, 64, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=str)
+def test_own_gemm_entries_vs_fp32_torch(dgtd, M, N, K, dtype):
+    """dgtd_gemm_bias / _bias_gelu / _bias_residual / _gelu_bwd and dgtd_transpose_batched through the C ABI against fp32 torch on the same
+    16-bit operands: 128- and 64-wide column tiles, one to 32 k-steps, both 16-bit types (cod.py:852-859, :900-921, :1097-1116)."""
+    import ctypes as C
+    L = dgtd._lib
+    code, st = L.dtype_code(torch.empty(1, dtype=dtype)), L.stream_ptr()
+    assert L.load().dgtd_gemm_supported(M, N, K, code) == 1 and L.load().dgtd_gemm_supported(M + 1, N, K, code) == 0
+    x = (_rand(M, K, seed=1) * 0.5).to(dtype)
+    w = (_rand(N, K, seed=2) / math.sqrt(K)).to(dtype)
+    b = (0.1 * _rand(N, seed=3)).to(dtype)
+    tol = dict(atol=2e-2, rtol=2e-2)
+    ref = x.float() @ w.float().t() + b.float()
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    L.call("dgtd_gemm_bias", x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, code, st)
+    torch.testing.assert_close(out.float(), ref, **tol)
+    L.call("dgtd_gemm_bias", x.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, code, st)
+    torch.testing.assert_close(out.float(), ref - b.float(), **tol)
+    pre, h = torch.empty_like(out), torch.empty_like(out)
+    L.call("dgtd_gemm_bias_gelu", x.data_ptr(), w.data_ptr(), b.data_ptr(), pre.data_ptr(), h.data_ptr(), M, N, K, code, st)
+    torch.testing.assert_close(pre.float(), ref, **tol)
+    torch.testing.assert_close(h.float(), F.gelu(pre.float()), atol=1e-2, rtol=1e-2)          # GELU of the STORED pre-activation
+    h2 = torch.empty_like(out)
+    L.call("dgtd_gemm_bias_gelu", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, h2.data_ptr(), M, N, K, code, st)
+    assert torch.equal(h, h2)
+    B = 2
+    res = _rand(M, N, seed=4, dtype=dtype)
+    s = torch.tensor([0.0, 1.25], device="cuda")
+    gamma = 0.5 + 0.1 * _rand(N, seed=5)
+    y, o = torch.empty_like(out), torch.empty_like(out)
+    L.call("dgtd_gemm_bias_residual", x.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), s.data_ptr(), gamma.data_ptr(), y.data_ptr(),
+           o.data_ptr(), M, N, K, M // B, code, st)
+    torch.testing.assert_close(y.float(), ref, **tol)
+    want = res.float() + s.repeat_interleave(M // B)[:, None] * gamma[None, :] * y.float()
+    torch.testing.assert_close(o.float(), want, **tol)
+    L.call("dgtd_gemm_bias_residual", x.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), None, None, None, o.data_ptr(), M, N, K, 1, code, st)
+    torch.testing.assert_close(o.float(), res.float() + ref, **tol)
+    # input gradient through the GELU: dpre = (dy W) * gelu'(pre) on the transposed copy of W, + column partials
+    dy = (0.1 * _rand(M, N, seed=6)).to(dtype)            # gradient of a Linear [N -> ...] whose INPUT is gelu(pre [M, K2]); here K2 := K
+    w2 = (_rand(N, K, seed=7) / math.sqrt(N)).to(dtype)   # that Linear's weight [out = N, in = K]
+    w2t = torch.empty(K, N, device="cuda", dtype=dtype)
+    P, I = C.c_void_p * 1, C.c_int * 1
+    L.call("dgtd_transpose_batched", P(w2.data_ptr()), P(w2t.data_ptr()), I(N), I(K), 1, code, st)
+    assert torch.equal(w2t, w2.t().contiguous())
+    prek = (_rand(M, K, seed=8)).to(dtype)
+    dpre = torch.empty(M, K, device="cuda", dtype=dtype)
+    if L.load().dgtd_gemm_supported(M, K, N, code):
+        ws = torch.empty(L.load().dgtd_gemm_gelu_bwd_workspace(M, K) // 4, device="cuda", dtype=torch.float32)
+        nb = C.c_int(0)
+        L.call("dgtd_gemm_gelu_bwd", dy.data_ptr(), w2t.data_ptr(), prek.data_ptr(), dpre.data_ptr(), ws.data_ptr(), C.byref(nb), M, K, N, code, st)
+        p32 = prek.float().requires_grad_()
+        F.gelu(p32).backward(dy.float() @ w2.float())
+        torch.testing.assert_close(dpre.float(), p32.grad, atol=2e-3, rtol=2e-2)
+        torch.testing.assert_close(ws.view(nb.value, K).sum(0), dpre.float().sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,C", [(1024, 128), (8192, 512), (2048, 1024)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=str)
+@pytest.mark.parametrize("with_s", [True, False])
+def test_mlp_residual_fused_node(dgtd, rows, C, dtype, with_s):
+    """x + s*gamma*(gelu(v W1^T + b1) W2^T + b2) as ONE node (convnext_Block's pointwise half, cod.py:1097-1116): value and every
+    gradient (dv, dW1, db1, dW2, db2, dx, dgamma) vs fp32 torch; the same tolerances as the two-node form it replaces."""
+    B, H4 = 2, 4 * C
+    v = _rand(B, rows // B, C, seed=1, dtype=dtype)
+    x = _rand(B, rows // B, C, seed=5, dtype=dtype)
+    w1 = (_rand(H4, C, seed=2) / math.sqrt(C)).to(dtype).requires_grad_()
+    b1 = (0.1 * _rand(H4, seed=3)).to(dtype).requires_grad_()
+    w2 = (_rand(C, H4, seed=7) / math.sqrt(H4)).to(dtype).requires_grad_()
+    b2 = (0.1 * _rand(C, seed=8)).to(dtype).requires_grad_()
+    s = torch.tensor([0.0, 1.25], device="cuda") if with_s else None
+    gamma = (0.5 + 0.1 * _rand(C, seed=6)).requires_grad_()
+    g = _rand(B, rows // B, C, seed=4, dtype=dtype)
+    vr, xr = v.float().requires_grad_(), x.float().requires_grad_()
+    p32 = [t.detach().float().requires_grad_() for t in (w1, b1, w2, b2)]
+    y = F.linear(F.gelu(F.linear(vr, p32[0], p32[1])), p32[2], p32[3]) * gamma
+    if with_s:
+        y = y * s.view(B, 1, 1)
+    ref = xr + y
+    rg = torch.autograd.grad(ref, [vr, xr, *p32, gamma], g.float())
+    vs, xs = v.clone().requires_grad_(), x.clone().requires_grad_()
+    assert dgtd.ops._native.ops().gemm_ok(rows, H4, C, dgtd._lib.dtype_code(v)), "shape must take the fused node"
+    out = dgtd.ops.mlp_residual(vs, w1, b1, w2, b2, xs, s, gamma)
+    got = torch.autograd.grad(out, [vs, xs, w1, b1, w2, b2, gamma], g)
+    tol = 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    names = ["dv", "dx", "dW1", "db1", "dW2", "db2", "dgamma"]
+    for n, a, b_ in zip(names, got, rg):
+        scale = math.sqrt(rows) if n in ("dW1", "db1", "dW2", "db2", "dgamma") else 1.0
+        torch.testing.assert_close(a.float(), b_, atol=tol * scale, rtol=tol, msg=lambda m, n=n: f"{n}: {m}")
