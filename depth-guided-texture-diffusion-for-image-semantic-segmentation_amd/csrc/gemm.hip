@@ -21,6 +21,7 @@
 // all epilogue arithmetic in fp32 with ONE rounding per output.  blockIdx -> tile mapping is XCD-aware (the column tiles of one row
 // panel of A run on one XCD's L2).  MFMA-bound above K ~ 512, HBM-bound below: 2·M·N·K flop over (M·K + N·K + n_out·M·N + ...)·e bytes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -51,14 +52,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BN, int EPI>
+// NSTAGE = 2: the next tile's DMA is issued at the top of a step, two barriers per step, 64 KB of LDS (two workgroups per CU cover each
+// other's stalls).  NSTAGE = 3: the DMA of tile kt + 2 is issued in slices BEHIND the MFMA groups of step kt (its issue slots hide
+// under the matrix pipe), two tiles in flight, ONE barrier per step, 96 KB of LDS.
+template <typename T, int BN, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
   typedef typename Vec16<T>::type V8;
   constexpr int WM = BN == 128 ? 64 : 32;                  // wave tile rows: 2x2 waves of 64x64, or 4x1 waves of 32x64
   constexpr int MI = WM / 32, NI = 2;                       // 32x32 MFMA tiles per wave
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int SROW = BN * 4 + 16;                         // fp32 staging row stride in bytes (+16: conflict-free 16-byte column writes)
-  constexpr int LDS_BYTES = 2 * STAGE > BM * SROW ? 2 * STAGE : BM * SROW;
+  constexpr int LDS_BYTES = NSTAGE * STAGE > BM * SROW ? NSTAGE * STAGE : BM * SROW;
   constexpr int A_PER_WAVE = (BM / 8) / 4, B_PER_WAVE = (BN / 8) / 4;   // 1-KiB DMA pieces (8 rows x 128 B) per wave and stage
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];       // the ONLY LDS object (a second one de-pipelines the DMA waits)
 
@@ -69,7 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
   const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases become scalar arithmetic
   const int K = g.K;
 
   const T* Ag = (const T*)g.A + (size_t)m0 * K;
@@ -86,15 +91,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
     const int row = (wave * B_PER_WAVE + p) * 8 + (lane >> 3);
     b_off[p] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
   }
-  auto stage = [&](int kt, int st) {
+  constexpr int PIECES = A_PER_WAVE + B_PER_WAVE;
+  // pieces [p0, p1) of this wave's share of tile kt -> stage st (A pieces first); the k offset rides on the UNIFORM base pointer
+  auto stage_part = [&](int kt, int st, int p0, int p1) {
     char* sa = lds + st * STAGE;
     char* sb = sa + A_BYTES;
-    const int k0 = kt * BK;
+    const T* Ak = Ag + kt * BK;
+    const T* Bk = Bg + kt * BK;
 #pragma unroll
-    for (int p = 0; p < A_PER_WAVE; ++p) glds16(Ag + a_off[p] + k0, sa + (wave * A_PER_WAVE + p) * 1024);
-#pragma unroll
-    for (int p = 0; p < B_PER_WAVE; ++p) glds16(Bg + b_off[p] + k0, sb + (wave * B_PER_WAVE + p) * 1024);
+    for (int p = 0; p < PIECES; ++p) {
+      if (p < p0 || p >= p1) continue;
+      if (p < A_PER_WAVE) glds16(Ak + a_off[p], sa + (wave * A_PER_WAVE + p) * 1024);
+      else glds16(Bk + b_off[p - A_PER_WAVE], sb + (wave * B_PER_WAVE + (p - A_PER_WAVE)) * 1024);
+    }
   };
+  auto stage = [&](int kt, int st) { stage_part(kt, st, 0, PIECES); };
 
   const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
   const int r = lane & 31, h = lane >> 5;
@@ -114,38 +125,67 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   const int nk = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < nk) {
-      stage(kt + 1, st ^ 1);                               // its buffer was last read before the closing barrier of step kt - 1
-      wait_vmcnt<A_PER_WAVE + B_PER_WAVE>();               // all but the pieces just issued: tile kt has landed (this wave's share)
-    } else {
-      wait_vmcnt<0>();
+  // one k-slice group: fragments double-buffered in registers (the reads of slice kk + 1 fly while the MFMAs of slice kk issue)
+  V8 af[2][MI], bf[2][NI];
+  auto frags = [&](const char* sa, const char* sb, int kk, int set) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const V8*>(sa + a_row[mi] + (((2 * kk + h) ^ a_sw[mi]) << 4));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const V8*>(sb + b_row[ni] + (((2 * kk + h) ^ b_sw[ni]) << 4));
+  };
+  auto mfmas = [&](int set) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(bf[set][ni], af[set][mi], acc[mi][ni]);   // D^T tile: lane & 31 = output ROW
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (NSTAGE == 2) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int st = kt & 1;
+      if (kt + 1 < nk) {
+        stage(kt + 1, st ^ 1);                             // its buffer was last read before the closing barrier of step kt - 1
+        wait_vmcnt<PIECES>();                              // all but the pieces just issued: tile kt has landed (this wave's share)
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();                        // ... and everybody else's share
+      const char* sa = lds + st * STAGE;
+      const char* sb = sa + A_BYTES;
+      frags(sa, sb, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        if (kk + 1 < BK / 16) frags(sa, sb, kk + 1, (kk + 1) & 1);
+        mfmas(kk & 1);
+      }
+      __builtin_amdgcn_s_barrier();                        // every wave is done reading stage st before step kt + 1 refills it
     }
-    __builtin_amdgcn_s_barrier();                          // ... and everybody else's share
-    const char* sa = lds + st * STAGE;
-    const char* sb = sa + A_BYTES;
-    // fragments double-buffered in registers: the reads of k-slice kk + 1 are in flight while the MFMAs of slice kk issue
-    V8 af[2][MI], bf[2][NI];
-    auto frags = [&](int kk, int set) {
+  } else {
+    // prologue: tiles 0 and 1 in flight
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();   // tile kt landed (this wave's share); tile kt + 1 may still fly
+      __builtin_amdgcn_s_barrier();                        // everybody's share landed AND everybody finished reading step kt - 1's stage,
+                                                           // which is the stage tile kt + 2 is about to overwrite
+      const char* sa = lds + st * STAGE;
+      const char* sb = sa + A_BYTES;
+      const int st2 = st == 0 ? 2 : st - 1;                // (kt + 2) % 3
+      const bool more = kt + 2 < nk;
+      frags(sa, sb, 0, 0);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const V8*>(sa + a_row[mi] + (((2 * kk + h) ^ a_sw[mi]) << 4));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const V8*>(sb + b_row[ni] + (((2 * kk + h) ^ b_sw[ni]) << 4));
-    };
-    frags(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      if (kk + 1 < BK / 16) frags(kk + 1, (kk + 1) & 1);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(bf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni]);   // D^T tile: lane & 31 = output ROW
-      __builtin_amdgcn_s_setprio(0);
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        if (kk + 1 < BK / 16) frags(sa, sb, kk + 1, (kk + 1) & 1);
+        mfmas(kk & 1);
+        // a quarter of the DMA of tile kt + 2, issued behind this group's MFMAs
+        if (more) stage_part(kt + 2, st2, (PIECES * kk) / (BK / 16), (PIECES * (kk + 1)) / (BK / 16));
+      }
+      st = st == 2 ? 0 : st + 1;
     }
-    __builtin_amdgcn_s_barrier();                          // every wave is done reading stage st before step kt + 1 refills it
+    __builtin_amdgcn_s_barrier();                          // all fragment reads done before the staging tile overwrites the stages
   }
 
   // ---- accumulators -> fp32 staging tile [BM][BN] in LDS (the operand stages are dead after the closing barrier)
@@ -254,19 +294,25 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(TrTable t) {
     if (tc0 + y < C && tr0 + x < R) d[(size_t)(tc0 + y) * R + tr0 + x] = tile[x][y];
 }
 
+// A/B knobs (read once): DGTD_GEMM_STAGES = 2 | 3 (pipeline form), DGTD_GEMM_WIDE_MIN = fewest 128-wide tiles for which the wide tile is taken
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 template <typename T, int EPI>
 int launch(const GemmArgs& a0, hipStream_t st) {
+  static const int force_stages = env_int("DGTD_GEMM_STAGES", 0), wide_min = env_int("DGTD_GEMM_WIDE_MIN", 192);
   GemmArgs a = a0;
   const int tiles_m = a.M / BM;
   // 128-wide column tiles when they alone fill the chip, 64-wide otherwise (N not a multiple of 128, or too few tiles)
-  const bool wide = a.N % 128 == 0 && (int64_t)tiles_m * (a.N / 128) >= 192;
-  if (wide) {
-    a.tiles_n = a.N / 128;
-    hipLaunchKernelGGL((gemm_tn_kernel<T, 128, EPI>), dim3(tiles_m * a.tiles_n), dim3(256), 0, st, a);
-  } else {
-    a.tiles_n = a.N / 64;
-    hipLaunchKernelGGL((gemm_tn_kernel<T, 64, EPI>), dim3(tiles_m * a.tiles_n), dim3(256), 0, st, a);
-  }
+  const bool wide = a.N % 128 == 0 && (int64_t)tiles_m * (a.N / 128) >= wide_min;
+  a.tiles_n = a.N / (wide ? 128 : 64);
+  // measured (tools/bench_gemm_own.py, profiles/r03_gemm_variants.txt): with at most one wide tile per CU no second workgroup covers a
+  // workgroup's stalls, and the deeper 3-stage pipeline wins (8192x512x2048: 22.6 vs 25.3 us); with more tiles two co-resident
+  // 2-stage workgroups per CU do (4096^3: 893 vs 761 TF/s)
+  const int stages = force_stages ? force_stages : ((wide && tiles_m * a.tiles_n <= 256) ? 3 : 2);
+  const dim3 grid(tiles_m * a.tiles_n), block(256);
+  if (wide && stages == 3) hipLaunchKernelGGL((gemm_tn_kernel<T, 128, EPI, 3>), grid, block, 0, st, a);
+  else if (wide) hipLaunchKernelGGL((gemm_tn_kernel<T, 128, EPI, 2>), grid, block, 0, st, a);
+  else if (stages == 3) hipLaunchKernelGGL((gemm_tn_kernel<T, 64, EPI, 3>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<T, 64, EPI, 2>), grid, block, 0, st, a);
   DGTD_CHECK_LAUNCH("gemm_tn");
   return 0;
 }

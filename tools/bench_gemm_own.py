@@ -23,6 +23,7 @@ SHAPES = [
     ("pvt1.fc1", 131072, 512, 64), ("pvt1.fc2", 131072, 64, 512), ("pvt1.q", 131072, 64, 64),
     ("pvt2.fc1", 32768, 1024, 128), ("pvt2.fc2", 32768, 128, 1024), ("pvt2.q", 32768, 128, 128),
     ("pvt3.fc1", 8192, 1280, 320), ("pvt3.fc2", 8192, 320, 1280), ("pvt3.q", 8192, 320, 320), ("pvt3.kv", 2048, 640, 320),
+    ("sq4096", 4096, 4096, 4096), ("sq8192k1024", 8192, 8192, 1024),
     ("pvt4.fc1", 2048, 2048, 512), ("pvt4.fc2", 2048, 512, 2048), ("pvt4.q", 2048, 512, 512), ("pvt4.kv", 2048, 1024, 512),
 ]
 
@@ -43,6 +44,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only-shapes", action="store_true")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     code = L.dtype_code(torch.empty(1, dtype=dt))
@@ -74,6 +76,8 @@ def main():
         tot_lib += tl
         print(f"{name:14s} {M:7d} {N:5d} {K:5d} | {to:8.1f} {fl / to / 1e6:6.0f} | {tl:8.1f} {fl / tl / 1e6:6.0f} | {tl / to:5.2f} | {e_own:.3e} {e_lib:.3e}")
     print(f"sum: own {tot_own:.0f} us, library {tot_lib:.0f} us")
+    if args.only_shapes:
+        return
 
     # ---- fused epilogues at the dominant ConvNeXt stage-2 shape
     M, C4, Cc = 8192, 2048, 512
