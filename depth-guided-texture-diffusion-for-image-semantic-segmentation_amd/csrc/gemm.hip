@@ -188,6 +188,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_barrier();                          // all fragment reads done before the staging tile overwrites the stages
   }
 
+  // the epilogue's tensor operand (residual x / saved pre-activation): every 16-byte chunk this thread will need is requested NOW, so
+  // the HBM latency runs under the accumulator staging instead of once per row pass
+  constexpr int CPR = BN / 8, RPP = 256 / CPR, NPASS = BM / RPP;   // chunks per row, rows per pass, passes
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int ncol = n0 + cc * 8;
+  V8 xin[NPASS];
+  if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) xin[i] = *reinterpret_cast<const V8*>((const T*)g.X + (size_t)(m0 + r0 + i * RPP) * g.N + ncol);
+  }
+
   // ---- accumulators -> fp32 staging tile [BM][BN] in LDS (the operand stages are dead after the closing barrier)
   // lane (r, h) holds, for output row m = r of its 32-row block, columns 8 q + 4 h + {0..3} (registers 4q .. 4q+3)
 #pragma unroll
@@ -206,9 +217,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
   __syncthreads();
 
   // ---- row-major epilogue: thread = one 8-column chunk, rows tid / CPR + i * RPP
-  constexpr int CPR = BN / 8, RPP = 256 / CPR;             // chunks per row, rows per pass
-  const int cc = tid % CPR, r0 = tid / CPR;
-  const int ncol = n0 + cc * 8;
   float bias[8], gam[8], csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bias[e] = 0.f; gam[e] = 1.f; csum[e] = 0.f; }
@@ -221,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) gam[e] = g.gamma[ncol + e];
   }
-#pragma unroll 2
-  for (int i = 0; i < BM / RPP; ++i) {
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
     const int row = r0 + i * RPP;
     const char* sp = lds + row * SROW + cc * 32;
     const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 16);
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
       if (g.D) *reinterpret_cast<V8*>((T*)g.D + o) = pre;
       *reinterpret_cast<V8*>((T*)g.D2 + o) = out;
     } else if (EPI == EPI_RESIDUAL) {
-      const V8 xv = *reinterpret_cast<const V8*>((const T*)g.X + o);
+      const V8 xv = xin[i];
       const float sc = g.s ? g.s[(m0 + row) / g.rows_per_sample] : 1.f;
       V8 y;
 #pragma unroll
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
       if (g.D2) *reinterpret_cast<V8*>((T*)g.D2 + o) = y;
       *reinterpret_cast<V8*>((T*)g.D + o) = out;
     } else {                                                 // EPI_GELU_BWD
-      const V8 pv = *reinterpret_cast<const V8*>((const T*)g.X + o);
+      const V8 pv = xin[i];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         out[e] = (T)(v[e] * gelu_grad_fast((float)pv[e]));

@@ -12,6 +12,8 @@
 #include <mutex>
 #include <vector>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <torch/autograd.h>
 #include <torch/csrc/autograd/engine.h>
 #include <torch/library.h>
@@ -369,7 +371,59 @@ static void flush_convs(std::vector<PendingConv>& cs, const std::map<const void*
 }
 
 static std::atomic<int64_t> g_flushed{0};
+// ASYNCHRONOUS FLUSH: the parked weight-gradient work is a handful of LARGE launches (batched GEMMs over 27 layers, batched depthwise
+// and 3x3 weight gradients: ~4.4 ms per step at config 2) that nothing in the backward pass waits for, while the backward pass itself
+// is a chain of small latency-bound launches that leave most of the chip idle.  flush_deferred_async() runs everything parked so far
+// on a SIDE stream forked from the caller's stream (event edges both ways, so it is captured into a hipGraph as a parallel branch);
+// the next synchronous flush - at the latest the end-of-backward callback - joins it.  The caller picks a point where no shared
+// deferral is half-way (dgtd.nn: when the gradient of the texture-diffuser embedding arrives, i.e. after the Hitnet decoder, every PVT
+// block and the prompt decoders have run backward, with the whole ConvNeXt trunk still to go).
+// Tensors the side stream reads are recorded on it (the caching allocator must not hand their memory to main-stream allocations
+// while the side stream is still running); the library-GEMM context is per stream (gemm.h).
+static c10::optional<c10::hip::HIPStream> g_side_stream;
+static hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;     // plain HIP events (record / stream-wait are capturable)
+static bool g_async_outstanding = false;
+static thread_local const c10::hip::HIPStream* t_record_on = nullptr;
+inline void keep_for_side(const Tensor& t) {
+  if (t_record_on && t.defined() && t.has_storage() && t.is_cuda()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), *t_record_on);
+}
+static void join_async() {
+  if (!g_async_outstanding) return;
+  TORCH_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), g_join_event, 0) == hipSuccess, "dgtd: joining the side stream failed");
+  g_async_outstanding = false;
+}
+static void flush_deferred_impl();
 void flush_deferred() {
+  join_async();
+  flush_deferred_impl();
+}
+void flush_deferred_async() {
+  static const bool on = [] { const char* e = std::getenv("DGTD_ASYNC_FLUSH"); return !e || std::atoi(e) != 0; }();
+  if (!on) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    if (g_pending.empty() && g_pending_dw.empty() && g_pending_gemm.empty() && g_pending_conv.empty()) return;
+  }
+  join_async();                                     // one side branch at a time
+  const auto cur = c10::hip::getCurrentHIPStream();
+  if (!g_side_stream || g_side_stream->device_index() != cur.device_index()) g_side_stream = c10::hip::getStreamFromPool(false, cur.device_index());
+  if (!g_fork_event) {
+    TORCH_CHECK(hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) == hipSuccess, "dgtd: hipEventCreate failed");
+  }
+  // the side stream sees everything enqueued so far (partials, saved activations)
+  TORCH_CHECK(hipEventRecord(g_fork_event, cur.stream()) == hipSuccess && hipStreamWaitEvent(g_side_stream->stream(), g_fork_event, 0) == hipSuccess,
+              "dgtd: forking the side stream failed");
+  {
+    c10::hip::HIPStreamGuard guard(*g_side_stream);
+    t_record_on = &*g_side_stream;
+    try { flush_deferred_impl(); } catch (...) { t_record_on = nullptr; throw; }
+    t_record_on = nullptr;
+  }
+  TORCH_CHECK(hipEventRecord(g_join_event, g_side_stream->stream()) == hipSuccess, "dgtd: recording the join event failed");
+  g_async_outstanding = true;
+}
+static void flush_deferred_impl() {
   {
     std::vector<PendingConv> convs;
     std::map<const void*, ConvDest> dest;
@@ -381,6 +435,7 @@ void flush_deferred() {
       g_conv_flip.clear();
     }
     g_flushed += (int64_t)convs.size();
+    for (auto& c : convs) { keep_for_side(c.x); keep_for_side(c.dy); keep_for_side(c.mask); }
     if (!convs.empty()) flush_convs(convs, dest);
   }
   std::vector<PendingReduce> todo;
@@ -390,6 +445,7 @@ void flush_deferred() {
     std::lock_guard<std::mutex> lk(g_pending_mu);
     gemms.swap(g_pending_gemm);
   }
+  for (auto& gm : gemms) { keep_for_side(gm.x); keep_for_side(gm.dy); }
   if (!gemms.empty()) flush_gemms(gemms);
   {
     std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -397,6 +453,8 @@ void flush_deferred() {
     dws.swap(g_pending_dw);
   }
   g_flushed += (int64_t)(gemms.size() + todo.size() + dws.size());
+  for (auto& p : todo) keep_for_side(p.ws);
+  for (auto& d : dws) { keep_for_side(d.x); keep_for_side(d.du); }
   if (todo.empty() && dws.empty()) return;
   std::vector<dgtd_reduce_entry> es;
   es.reserve(todo.size() + dws.size());
@@ -1518,6 +1576,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("bilinear_resize(Tensor x, int oh, int ow, bool align) -> Tensor", &bilinear_resize);
   m.def("set_deferred(bool on) -> ()", &set_deferred);
   m.def("flush_deferred() -> ()", &flush_deferred);
+  m.def("flush_deferred_async() -> ()", &flush_deferred_async);
   m.def("pending_reductions() -> int", &pending_reductions);
   m.def("flushed_reductions() -> int", &flushed_reductions);
   m.def("set_shared_deferral(bool on) -> ()", &set_shared_deferral);

@@ -68,9 +68,13 @@ inline bool exhaustive() {
   return on;
 }
 
-inline Ctx& ctx() {   // never destroyed: a thread_local destructor could run after the HIP runtime has shut down
-  thread_local Ctx* c = new Ctx();
-  return *c;
+// One context (handle, plan cache, 64 MB workspace) per thread AND stream: the deferred weight-gradient phase can run on a side stream
+// beside the backward pass (bindings.cpp flush_deferred_async); two GEMMs in flight on different streams must not share a workspace.
+inline Ctx& ctx(hipStream_t st) {   // never destroyed: a thread_local destructor could run after the HIP runtime has shut down
+  thread_local std::unordered_map<hipStream_t, Ctx*>* m = new std::unordered_map<hipStream_t, Ctx*>();
+  auto it = m->find(st);
+  if (it == m->end()) it = m->emplace(st, new Ctx()).first;
+  return *it->second;
 }
 
 inline bool ok(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS; }
@@ -86,7 +90,7 @@ inline bool matmul_16(at::ScalarType half_type, const void* A, const void* B, vo
                       bool transA, bool transB, int batch, int64_t sA, int64_t sB, int64_t sD, const at::TensorOptions& dev_opts, hipStream_t st) {
   if (!enabled()) return false;
   const hipDataType DT = half_type == at::kHalf ? HIP_R_16F : HIP_R_16BF;
-  Ctx& c = ctx();
+  Ctx& c = ctx(st);
   if (c.dead) return false;
   if (!c.handle) {
     uint64_t wsz = kWorkspace;

@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused", "async_flush")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -544,6 +544,13 @@ class PyramidVisionTransformerImpr(nn.Module):
         image = x
         embedding1, embedding3 = self.prompt_encoder(image, depth, x_hp=x_hp)
         embedding3 = embedding3.contiguous(memory_format=torch.channels_last)
+        if _USE["async_flush"] and embedding3.requires_grad and embedding3.is_cuda:
+            # backward: when this gradient arrives, the Hitnet decoder, every PVT block and the prompt decoders are done and the whole
+            # ConvNeXt trunk is still to go - their parked weight-gradient work (batched GEMMs, depthwise / 3x3 weight gradients) starts
+            # on a side stream now and runs beside the ConvNeXt backward pass instead of after it (bindings.cpp flush_deferred_async)
+            nat = ops._native.ops()
+            if nat is not None:
+                embedding3.register_hook(_async_flush_hook)
         trunks, off = self._prompt_trunks(embedding3), 0
         outs = []
         for i in range(4):
@@ -577,6 +584,13 @@ class PyramidVisionTransformerImpr(nn.Module):
 
     def forward(self, x, depth, x_hp=None):
         return self.forward_features(x, depth, x_hp)
+
+
+def _async_flush_hook(grad):
+    nat = ops._native.ops()
+    if nat is not None:
+        nat.flush_deferred_async()
+    return None
 
 
 def _pvt_variant(name, depths, mlp_ratios, doc):
