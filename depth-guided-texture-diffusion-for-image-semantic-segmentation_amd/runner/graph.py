@@ -188,6 +188,14 @@ class GraphedTrainStep:
                 r.zero_grad()                                                    # every leaf .grad is None when capture starts
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            if self.mode != "single":
+                # RCCL's watchdog thread polls the completion events of the eager collectives of the warm-up (every ~100 ms).  On ROCm 7
+                # hipEventQuery refuses an event whose STREAM has meanwhile entered capture (hipErrorCapturedEvent, even though the event
+                # was recorded before the capture began), and the watchdog turns that into process termination.  All warm-up work is
+                # complete here (synchronize above): give the watchdog a few polling periods to retire those entries before any of the
+                # process group's streams joins the capture.  (Collectives issued DURING capture are never handed to the watchdog.)
+                import time
+                time.sleep(0.5)
             self.graph_fb = torch.cuda.CUDAGraph()
             # with a process group alive, RCCL's watchdog thread keeps querying events while we capture: only this thread's (and the
             # autograd thread's, which launches into the capturing stream) calls must obey capture rules

@@ -51,10 +51,12 @@ def main():
         opt_e.step()
         losses.append(loss.item())
     out["eager"] = {"losses": losses}
+    print("eager done", flush=True)
     for mode in ("fused", "split"):
         net_g, red_g, opt_g = make()
         stepper = dgtd.runner.GraphedTrainStep(net_g, red_g, opt_g, warmup=2, comm=mode)
         stepper.capture(batches[0])
+        print(f"{mode}: captured", flush=True)
         assert stepper.mode == mode and (stepper.graph_opt is not None) == (mode == "split")
         assert red_g.overlap, "the reducer's own mode is restored after capture"
         losses = [stepper(batches[i]).item() for i in range(3)]
@@ -65,8 +67,10 @@ def main():
             worst = max(worst, float(d.max()))
             bad += int((d > 2e-5 + 1e-3 * q.abs()).sum())
         out[mode] = {"losses": losses, "max_weight_diff": worst, "elements_off": bad, "steps": opt_g.steps}
+        print(f"{mode}: replayed", flush=True)
         stepper.release()
         del net_g, red_g, opt_g, stepper
+        torch.cuda.synchronize()
     print("RESULT " + json.dumps(out), flush=True)
     torch.distributed.destroy_process_group()
 

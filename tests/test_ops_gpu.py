@@ -516,13 +516,21 @@ def test_dwconv_weight_gradients_deferred_and_batched(dgtd, K, L, B, H, W, C, dt
     other = (_rand(2, 8, 8, 128, seed=3, dtype=dtype), (_rand(128, 1, 3, 3, seed=4) / 3).to(dtype).requires_grad_(), None, _rand(2, 8, 8, 128, seed=5, dtype=dtype))
     nat.set_deferred(True)
     try:
-        got = []
+        # ONE backward pass over all layers: everything it parks is flushed together by the engine callback at its end
+        ys, params, gs = [], [], []
         for i, (x, w, b, g) in enumerate(layers + [other]):
-            y = dgtd.ops.dwconv_nhwc(x, w, b, False)
-            got.append(torch.autograd.grad(y, (w, b) if b is not None else (w,), g))
-        assert nat.pending_reductions() == L + 1
+            ys.append(dgtd.ops.dwconv_nhwc(x, w, b, False))
+            params.append((w, b) if b is not None else (w,))
+            gs.append(g)
+        done = nat.flushed_reductions()
+        flat = torch.autograd.grad(ys, [p for ps in params for p in ps], gs)
+        assert nat.flushed_reductions() - done == L + 1 and nat.pending_reductions() == 0
+        got, k = [], 0
+        for ps in params:
+            got.append(flat[k:k + len(ps)])
+            k += len(ps)
     finally:
-        nat.set_deferred(False)                                   # flushes
+        nat.set_deferred(False)
     assert nat.pending_reductions() == 0
     for (x, w, b, g), gr in zip(layers + [other], got):
         wr = w.detach().float().requires_grad_()
@@ -554,8 +562,9 @@ def test_conv3x3_weight_gradients_deferred_batched_and_shared(dgtd, half):
     nat.set_deferred(True)
     try:
         ys = [dgtd.ops.conv3x3(x, w, b) for ((w, b), S), (x, g) in zip(calls, xs)]
+        done = nat.flushed_reductions()
         torch.autograd.backward(ys, [g for _, g in xs])
-        assert nat.pending_reductions() == 4 + 4 + 1 + 2              # `we` runs at two geometries: not parked
+        assert nat.flushed_reductions() - done == 4 + 4 + 1 + 2       # `we` runs at two geometries: not parked; flushed at the end of the pass
     finally:
         nat.set_deferred(False)
     assert nat.pending_reductions() == 0
