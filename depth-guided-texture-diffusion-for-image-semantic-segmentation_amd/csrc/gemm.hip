@@ -40,6 +40,7 @@ struct GemmArgs {
   float* colsum;          // EPI_GELU_BWD: per-row-tile column partials [M/128][N] or NULL
   int M, N, K, tiles_n;
   int64_t rows_per_sample;
+  int dbg;                // tools only (DGTD_GEMM_DBG): 1 = one k-step instead of K / 64, 2 = no global stores in the epilogue
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  const int nk = K / BK;
+  const int nk = (g.dbg & 1) ? 1 : K / BK;
   // one k-slice group: fragments double-buffered in registers (the reads of slice kk + 1 fly while the MFMAs of slice kk issue)
   V8 af[2][MI], bf[2][NI];
   auto frags = [&](const char* sa, const char* sb, int kk, int set) {
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) gam[e] = g.gamma[ncol + e];
   }
+  const bool store = !(g.dbg & 2);
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     const int row = r0 + i * RPP;
@@ -242,21 +244,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
     if (EPI == EPI_BIAS) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) out[e] = (T)v[e];
-      *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      if (store) *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      else asm volatile("" ::"v"(out));
     } else if (EPI == EPI_GELU) {
       V8 pre;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { pre[e] = (T)v[e]; out[e] = (T)gelu_fast((float)pre[e]); }   // GELU of the STORED pre-activation: what the backward recomputes from
-      if (g.D) *reinterpret_cast<V8*>((T*)g.D + o) = pre;
-      *reinterpret_cast<V8*>((T*)g.D2 + o) = out;
+      if (g.D && store) *reinterpret_cast<V8*>((T*)g.D + o) = pre;
+      if (store) *reinterpret_cast<V8*>((T*)g.D2 + o) = out;
+      else asm volatile("" ::"v"(out), "v"(pre));
     } else if (EPI == EPI_RESIDUAL) {
       const V8 xv = xin[i];
       const float sc = g.s ? g.s[(m0 + row) / g.rows_per_sample] : 1.f;
       V8 y;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { y[e] = (T)v[e]; out[e] = (T)fmaf(sc * gam[e], (float)y[e], (float)xv[e]); }   // from the STORED y, like the backward
-      if (g.D2) *reinterpret_cast<V8*>((T*)g.D2 + o) = y;
-      *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      if (g.D2 && store) *reinterpret_cast<V8*>((T*)g.D2 + o) = y;
+      if (store) *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      else asm volatile("" ::"v"(out), "v"(y));
     } else {                                                 // EPI_GELU_BWD
       const V8 pv = xin[i];
 #pragma unroll
@@ -264,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
         out[e] = (T)(v[e] * gelu_grad_fast((float)pv[e]));
         csum[e] += (float)out[e];                            // the bias gradient sums the gradient the weight-gradient GEMM will read
       }
-      *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      if (store) *reinterpret_cast<V8*>((T*)g.D + o) = out;
+      else asm volatile("" ::"v"(out));
     }
   }
   if (EPI == EPI_GELU_BWD && g.colsum) {
@@ -306,8 +312,9 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(TrTable t) {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 template <typename T, int EPI>
 int launch(const GemmArgs& a0, hipStream_t st) {
-  static const int force_stages = env_int("DGTD_GEMM_STAGES", 0), wide_min = env_int("DGTD_GEMM_WIDE_MIN", 192);
+  static const int force_stages = env_int("DGTD_GEMM_STAGES", 0), wide_min = env_int("DGTD_GEMM_WIDE_MIN", 192), dbg = env_int("DGTD_GEMM_DBG", 0);
   GemmArgs a = a0;
+  a.dbg = dbg;
   const int tiles_m = a.M / BM;
   // 128-wide column tiles when they alone fill the chip, 64-wide otherwise (N not a multiple of 128, or too few tiles)
   const bool wide = a.N % 128 == 0 && (int64_t)tiles_m * (a.N / 128) >= wide_min;
