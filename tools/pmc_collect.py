@@ -21,9 +21,9 @@ for op in sorted(os.listdir(root)):
             if r["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d*|void ", "", r["Kernel_Name"])
-            if not any(k in name for k in ("dwconv", "ln_", "sra_", "attn_delta", "colsum", "conv3x3", "multi_reduce", "scale_residual")):
+            if not any(k in name for k in ("dwconv", "ln_", "sra_", "attn_delta", "colsum", "conv3x3", "multi_reduce", "scale_residual", "gemm_tn")):
                 continue
-            e = per.setdefault(name[:60] + " grid=" + r["Grid_Size"], {"fetch": [0.0, 0], "write": [0.0, 0]})
+            e = per.setdefault(name[:72] + " grid=" + r["Grid_Size"], {"fetch": [0.0, 0], "write": [0.0, 0]})
             e[kind][0] += float(r["Counter_Value"]) * 1024 * (2 if kind == "fetch" else 1)
             e[kind][1] += 1
     out[op] = {k: {"fetch_bytes": round(v["fetch"][0] / max(v["fetch"][1], 1)), "write_bytes": round(v["write"][0] / max(v["write"][1], 1)),
@@ -32,6 +32,12 @@ print(json.dumps(out, indent=1))
 
 # ---- second output (stderr -> file): HBM bytes per C-ABI call keyed like bench.py's kernel keys
 BENCH_KEYS = {
+    # the package's own GEMM at the ConvNeXt stage-3 shape (template arguments: <T, BN, EPI, NSTAGE>; EPI 1 = bias+GELU, 2 = bias+residual,
+    # 3 = through-GELU input gradient, 0 = plain: here the input gradient of pwconv1)
+    "dgtd_gemm_bias_gelu[M=8192,N=2048,K=512]": ("mlp_residual_8192x512", ["Li128ELi1E"]),
+    "dgtd_gemm_bias_residual[M=8192,N=512,K=2048]": ("mlp_residual_8192x512", ["Li128ELi2E"]),
+    "dgtd_gemm_gelu_bwd[M=8192,N=2048,K=512]": ("mlp_residual_8192x512", ["Li128ELi3E"]),
+    "dgtd_gemm_bias[M=8192,N=512,K=2048]": ("mlp_residual_8192x512", ["Li128ELi0E"]),
     "dgtd_gelu_bias_bwd[rows=8192,C=2048]": ("linear_gelu_8192x512x2048", ["colsum2_kernel"]),
     "dgtd_scale_residual_bias_bwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["colsum2_kernel"]),
     "dgtd_scale_residual_fwd[rows=8192,C=512]": ("linear_residual_8192x2048x512", ["scale_residual_fwd_kernel"]),

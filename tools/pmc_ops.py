@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-NATIVE_OPS = ("linear_gelu_8192x512x2048", "linear_residual_8192x2048x512", "dwconv_batched_k7_n27_32x32x512")   # nodes that only exist in the C++ bindings
+NATIVE_OPS = ("linear_gelu_8192x512x2048", "linear_residual_8192x2048x512", "dwconv_batched_k7_n27_32x32x512", "mlp_residual_8192x512")   # nodes that only exist in the C++ bindings
 os.environ.setdefault("DGTD_TORCH_BINDINGS", "1" if len(sys.argv) > 1 and sys.argv[1] in NATIVE_OPS else "0")
 import dgtd  # noqa: E402
 
@@ -96,7 +96,25 @@ def dw_batched(K, n, H, C):
         nat.set_deferred(False)
 
 
+def mlp_res(rows, C):
+    """convnext_Block's pointwise half as the ONE fused node on the package's own GEMM (csrc/gemm.hip): gemm_bias_gelu, gemm_bias_residual,
+    scale_residual_bias_bwd, gemm_gelu_bwd, gemm_bias (input gradient) + the library weight-gradient GEMMs."""
+    v = torch.randn(8, rows // 8, C, device=dev, dtype=bf).requires_grad_()
+    x = torch.randn(8, rows // 8, C, device=dev, dtype=bf).requires_grad_()
+    w1 = (torch.randn(4 * C, C, device=dev, dtype=bf) / C ** 0.5).requires_grad_()
+    b1 = torch.randn(4 * C, device=dev, dtype=bf).requires_grad_()
+    w2 = (torch.randn(C, 4 * C, device=dev, dtype=bf) / (4 * C) ** 0.5).requires_grad_()
+    b2 = torch.randn(C, device=dev, dtype=bf).requires_grad_()
+    gamma = torch.ones(C, device=dev).requires_grad_()
+    s = torch.ones(8, device=dev)
+    g = torch.randn(8, rows // 8, C, device=dev, dtype=bf)
+    for _ in range(REPS):
+        y = dgtd.ops.mlp_residual(v, w1, b1, w2, b2, x, s, gamma)
+        torch.autograd.grad(y, (v, x, w1, b1, w2, b2, gamma), g)
+
+
 OPS = {
+    "mlp_residual_8192x512": lambda: mlp_res(8192, 512),
     "linear_gelu_8192x512x2048": lambda: lin_gelu(8192, 512, 2048),
     "linear_residual_8192x2048x512": lambda: lin_res(8192, 2048, 512),
     "dwconv_batched_k7_n27_32x32x512": lambda: dw_batched(7, 27, 32, 512),
