@@ -353,8 +353,19 @@ class GradReducer:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 go()
+                # "this bucket is averaged and widened": what a per-bucket consumer (FlatAdamW in the pipelined captured step) waits for
+                ev = bucket.get("event")
+                if ev is None:
+                    ev = bucket["event"] = torch.cuda.Event()
+                ev.record(self.comm_stream)
         else:
             go()
+
+    def wait_bucket(self, index: int) -> None:
+        """Make the current stream wait until bucket ``index`` has been all-reduced (no-op when nothing was launched for it)."""
+        ev = self.buckets[index].get("event")
+        if ev is not None and self.comm_stream is not None and (self.world > 1 or self._force):
+            torch.cuda.current_stream().wait_event(ev)
 
     def finish(self) -> None:
         """Call after backward(): gathers/launches whatever the hooks did not (in bucket order), then fences the compute stream."""

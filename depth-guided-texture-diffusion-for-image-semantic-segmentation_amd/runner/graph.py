@@ -49,10 +49,15 @@ class _no_cat:
 class GraphedTrainStep:
     """``comm`` decides how the gradient all-reduce of an N > 1 job meets the captured step:
 
-    * ``"fused"``: the bucketed all-reduces are captured INSIDE the one graph, on the reducer's side stream: the autograd hooks gather
-      a bucket when its last gradient arrives and fork the collective (event edges comm_stream <- capture stream), ``finish()`` joins
-      it before AdamW.  The replayed graph then has the RCCL kernels as a parallel branch beside the rest of the backward pass - the
-      overlap of the eager mode without its host cost.  Needs a backend whose collectives are stream-ordered and capturable (RCCL).
+    * ``"fused"``: ONE graph with the collectives captured inside it.  After the backward pass (one flush of the deferred weight-gradient
+      phase: ~95 % of the gradient bytes are weight gradients that only exist after it) every bucket is gathered and its all-reduce is
+      forked onto the reducer's side stream at once; AdamW then walks the buckets and waits for each bucket's own all-reduce only.  In
+      the replayed graph the RCCL kernels of bucket i run beside the gather of buckets > i and the optimizer of buckets < i.  Needs a
+      backend whose collectives are stream-ordered and capturable (RCCL).
+    * ``"hooks"``: ONE graph as well, but the autograd hooks gather a bucket when its last gradient arrives and fork its collective
+      during the backward pass (the eager overlap mode, recorded).  The literal "overlap with backward" - and measured SLOWER: a gather
+      inside the backward pass must flush the parked weight-gradient work early, which chops the batched launches of the deferred
+      phase into per-bucket pieces and switches the shared deferrals off (profiles/r03_bench_forced_allreduce_*.json).
     * ``"split"``: graph A (forward / backward / gather) -> eager bucketed all-reduce -> graph B (AdamW); no overlap, works with any
       backend (the gloo tests).
     * ``"auto"``: fused with RCCL, split otherwise.  World 1 without DGTD_FORCE_ALLREDUCE: one graph, no collective.
@@ -73,8 +78,8 @@ class GraphedTrainStep:
         self.loss = None
         self._pinned, self._pinned_groups = False, []
         multi = reducer.world > 1 or reducer._force
-        if comm not in ("auto", "fused", "split"):
-            raise ValueError(f"comm must be auto, fused or split, got {comm!r}")
+        if comm not in ("auto", "fused", "hooks", "split"):
+            raise ValueError(f"comm must be auto, fused, hooks or split, got {comm!r}")
         if not multi:
             self.mode = "single"
         elif comm == "auto":
@@ -124,13 +129,28 @@ class GraphedTrainStep:
     def _one_step(self) -> torch.Tensor:
         """The step in the order the capture records it (also the eager warm-up)."""
         loss = self._fwd_bwd()
-        if self.mode == "fused":
-            self.reducer.finish()          # hooks gathered + launched during backward; stragglers, join, fence
+        r = self.reducer
+        if self.mode == "hooks":
+            r.finish()                     # hooks gathered + launched during backward; stragglers, join, fence
+            self.opt.step()
+        elif self.mode == "fused":
+            for b in r.buckets[r._next:]:  # gather + fork the collective, bucket after bucket (the first gather flushes the deferred phase)
+                r._gather(b)
+                r._launch(b)
+            r._next = len(r.buckets)
+            r._defer(False)
+            r._works.clear()               # captured collectives are ordered by the per-bucket events, not by Work.wait()
+            self.opt.pipelined = True
+            try:
+                self.opt.step()            # bucket i's AdamW waits for bucket i's all-reduce only
+            finally:
+                self.opt.pipelined = False
+            torch.cuda.current_stream().wait_stream(r.comm_stream)     # rejoin the side stream (capture: no unjoined branch)
         else:
             self._gather_all()
             if self.split:
                 self._allreduce_all()
-        self.opt.step()
+            self.opt.step()
         return loss
 
     # ------------------------------------------------------------------ state around the warm-up
@@ -170,9 +190,9 @@ class GraphedTrainStep:
         r = self.reducer
         overlap = r.overlap
         self._overlap_before = overlap
-        # fused: hooks gather + fork the collectives (eager overlap mode, recorded); otherwise hooks only count and gather / launch
-        # are explicit in _one_step
-        r.overlap = overlap if self.mode == "fused" else False
+        # hooks: the autograd hooks gather + fork the collectives (eager overlap mode, recorded); otherwise hooks only count and
+        # gather / launch are explicit in _one_step
+        r.overlap = overlap if self.mode == "hooks" else False
         try:
             s = self.stream
             s.wait_stream(torch.cuda.current_stream())

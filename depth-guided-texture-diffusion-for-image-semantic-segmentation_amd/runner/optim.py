@@ -88,6 +88,7 @@ class FlatAdamW:
         self.reducer, self.scaler = reducer, scaler
         custom_keys = SOD_CUSTOM_KEYS if custom_keys is None else custom_keys
         self.betas, self.eps, self.weight_decay, self._steps = betas, eps, weight_decay, 0
+        self.pipelined = False      # set by GraphedTrainStep(comm="fused"): every bucket's AdamW waits for that bucket's all-reduce only
         mults = sorted({lr_mult_for(n, custom_keys) for b in reducer.buckets for n in b["names"]}, reverse=True)
         self.param_groups = [{"lr": lr * m, "initial_lr": lr * m, "mult": m, "weight_decay": weight_decay} for m in mults]
         gidx = {m: i for i, m in enumerate(mults)}
@@ -153,9 +154,13 @@ class FlatAdamW:
         amp = self._state.data_ptr() if self._state is not None else None
         if self.scaler is not None:
             for b in self.reducer.buckets:          # GradScaler.unscale_'s found_inf over every (already all-reduced) gradient
+                if self.pipelined:
+                    self.reducer.wait_bucket(b["index"])
                 L.call("dgtd_found_inf", b["flat"].data_ptr(), b["flat"].numel(), amp + 12, st)
         lrp = self._lr_dev.data_ptr() if self._lr_dev is not None else None
         for b, slots, runs, state in zip(self.reducer.buckets, self.slots, self.runs, self.state):
+            if self.pipelined:                      # the bucket's all-reduce runs on the reducer's side stream: join it bucket by bucket
+                self.reducer.wait_bucket(b["index"])
             p, g, m, v, w, nw = b["mflat"], b["flat"], state["exp_avg"], state["exp_avg_sq"], b["wflat"], b["n_work"]
             # world 1: parameters without a gradient this step are skipped, like torch.optim.AdamW does.  N > 1: ``missing`` is
             # rank-local while the all-reduced slot holds the average over every rank (zero from the ranks that did not use the

@@ -52,7 +52,7 @@ def main():
         losses.append(loss.item())
     out["eager"] = {"losses": losses}
     print("eager done", flush=True)
-    for mode in ("fused", "split"):
+    for mode in ("fused", "hooks", "split"):
         net_g, red_g, opt_g = make()
         stepper = dgtd.runner.GraphedTrainStep(net_g, red_g, opt_g, warmup=2, comm=mode)
         stepper.capture(batches[0])

@@ -432,8 +432,9 @@ def test_batched_weight_gradient_gemms_match_per_layer_path(dgtd):
 def test_graphed_step_with_forced_allreduce(dtype):
     """the N > 1 forms of the captured step under a test.  A world-1 RCCL group (DGTD_FORCE_ALLREDUCE=1, own
     process so the communicator never meets the other tests) runs 3 steps eager with hook-driven bucket all-reduces, then the same
-    through GraphedTrainStep in both N > 1 modes: "fused" (collectives captured inside the one graph on the side stream) and
-    "split" (graph A | all-reduce | graph B).  fp32: same losses / weights as eager to atomic noise; bf16 (16-bit payload): close."""
+    through GraphedTrainStep in all N > 1 modes: "fused" (collectives captured inside the one graph, forked per bucket after the backward
+    pass and joined per bucket by AdamW), "hooks" (forked from the autograd hooks during the backward pass) and "split" (graph A |
+    all-reduce | graph B).  fp32: same losses / weights as eager to atomic noise; bf16 (16-bit payload): close."""
     import json
     import socket
     import subprocess
@@ -448,7 +449,7 @@ def test_graphed_step_with_forced_allreduce(dtype):
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
     tol = 1e-4 if dtype == "f32" else 2e-2
-    for mode in ("fused", "split"):
+    for mode in ("fused", "hooks", "split"):
         got, want = out[mode]["losses"], out["eager"]["losses"]
         print(f"[{dtype} {mode}] losses {got} vs eager {want}; max weight diff {out[mode]['max_weight_diff']:.2e}, elements off {out[mode]['elements_off']}")
         assert out[mode]["steps"] == 3

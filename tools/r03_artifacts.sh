@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 python3 bench.py --all-kernels $O/kernels_all.json > $O/bench.json 2> $O/bench.err
 echo "bench: $(python3 -c "import json;d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]);print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])")"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 bench.py --no-miou --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 bench.py --no-miou --no-cpu-baseline --profile-steps 0 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 T=$(ls $O/prof/*kernel_trace.csv | head -1)
 python3 tools/trace_summary.py $T --top 90 > $O/step_kernels.txt
 cp $O/prof/*kernel_stats.csv $O/bench_rocprof_kernel_stats.csv
