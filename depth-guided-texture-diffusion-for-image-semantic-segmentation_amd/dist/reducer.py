@@ -336,18 +336,16 @@ class GradReducer:
         parts = [flat] if g16 is None else ([g16] + ([flat[nw:]] if flat.numel() > nw else []))
 
         def go():
-            ws = []
+            # The process group runs a collective on its OWN internal stream (forked from the stream that is current at the call);
+            # Work.wait() makes the CURRENT stream - here the reducer's side stream - wait for it (a stream-level wait, the host does
+            # not block with RCCL; with gloo the host does).  Joined right here, so that (i) the widening copy below is ordered behind
+            # the all-reduce and (ii) under hipGraph capture the group's stream is joined back into the capture.
             for t in parts:
                 if not avg:
                     t.div_(self.world)
-                ws.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+                dist.all_reduce(t, op=op, group=self.group, async_op=True).wait()
             if g16 is not None:     # widen into the fp32 bucket the optimizer reads
-                if not avg:         # gloo: completion is not stream-ordered, join before reading the result
-                    for w in ws:
-                        w.wait()
-                    ws = []
-                flat[:nw].copy_(g16)   # RCCL: same stream as the all-reduce, ordered after it
-            self._works.extend(ws)
+                flat[:nw].copy_(g16)
 
         if self._cuda and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
