@@ -343,7 +343,11 @@ class GradReducer:
             for t in parts:
                 if not avg:
                     t.div_(self.world)
-                dist.all_reduce(t, op=op, group=self.group, async_op=True).wait()
+                w = dist.all_reduce(t, op=op, group=self.group, async_op=True)
+                w.wait()
+                self._works.append(w)   # kept until the end of the step: a Work that dies inside a hipGraph capture hands its completion event
+                                        # back to the process group's event cache, the next collective of the SAME capture re-records it, and
+                                        # hipStreamEndCapture crashes (ROCm 7.0 / RCCL 2.26; observed as a segfault in capture_end)
             if g16 is not None:     # widen into the fp32 bucket the optimizer reads
                 flat[:nw].copy_(g16)
 

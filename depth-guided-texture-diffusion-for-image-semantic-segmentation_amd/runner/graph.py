@@ -139,13 +139,13 @@ class GraphedTrainStep:
                 r._launch(b)
             r._next = len(r.buckets)
             r._defer(False)
-            r._works.clear()               # captured collectives are ordered by the per-bucket events, not by Work.wait()
             self.opt.pipelined = True
             try:
                 self.opt.step()            # bucket i's AdamW waits for bucket i's all-reduce only
             finally:
                 self.opt.pipelined = False
             torch.cuda.current_stream().wait_stream(r.comm_stream)     # rejoin the side stream (capture: no unjoined branch)
+            r._works.clear()
         else:
             self._gather_all()
             if self.split:
