@@ -336,38 +336,39 @@ class GradReducer:
         parts = [flat] if g16 is None else ([g16] + ([flat[nw:]] if flat.numel() > nw else []))
 
         def go():
-            # The process group runs a collective on its OWN internal stream (forked from the stream that is current at the call);
-            # Work.wait() makes the CURRENT stream - here the reducer's side stream - wait for it (a stream-level wait, the host does
-            # not block with RCCL; with gloo the host does).  Joined right here, so that (i) the widening copy below is ordered behind
-            # the all-reduce and (ii) under hipGraph capture the group's stream is joined back into the capture.
+            # The process group runs a collective on its OWN internal stream (forked from the stream that is current at the call); only
+            # Work.wait() orders anything behind it.  The consumer joins per bucket (wait_bucket): the optimizer's stream waits for the
+            # bucket's collectives and THEN widens the 16-bit payload into the fp32 bucket - never on this side stream, where nothing
+            # would order the copy behind the all-reduce.
             for t in parts:
                 if not avg:
                     t.div_(self.world)
-                w = dist.all_reduce(t, op=op, group=self.group, async_op=True)
-                w.wait()
-                self._works.append(w)   # kept until the end of the step: a Work that dies inside a hipGraph capture hands its completion event
-                                        # back to the process group's event cache, the next collective of the SAME capture re-records it, and
-                                        # hipStreamEndCapture crashes (ROCm 7.0 / RCCL 2.26; observed as a segfault in capture_end)
-            if g16 is not None:     # widen into the fp32 bucket the optimizer reads
-                flat[:nw].copy_(g16)
+                bucket["works"].append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
 
+        bucket["works"] = []
         if self._cuda and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 go()
-                # "this bucket is averaged and widened": what a per-bucket consumer (FlatAdamW in the pipelined captured step) waits for
-                ev = bucket.get("event")
-                if ev is None:
-                    ev = bucket["event"] = torch.cuda.Event()
-                ev.record(self.comm_stream)
         else:
             go()
 
+    @torch.no_grad()
     def wait_bucket(self, index: int) -> None:
-        """Make the current stream wait until bucket ``index`` has been all-reduced (no-op when nothing was launched for it)."""
-        ev = self.buckets[index].get("event")
-        if ev is not None and self.comm_stream is not None and (self.world > 1 or self._force):
-            torch.cuda.current_stream().wait_event(ev)
+        """Make the CURRENT stream wait for bucket ``index``'s all-reduce and widen its 16-bit payload into the fp32 bucket (no-op when
+        nothing was launched for it).  With RCCL the wait is a stream-level event wait (capturable); with gloo the host blocks."""
+        b = self.buckets[index]
+        works = b.get("works")
+        if not works:
+            return
+        for w in works:
+            w.wait()
+        # the Work objects stay alive until the end of the step (a Work that dies inside a hipGraph capture returns its completion
+        # event to the process group's cache, where the next collective of the same capture would re-record it)
+        self._works.extend(works)
+        b["works"] = []
+        if b["g16"] is not None:
+            b["flat"][:b["n_work"]].copy_(b["g16"])
 
     def finish(self) -> None:
         """Call after backward(): gathers/launches whatever the hooks did not (in bucket order), then fences the compute stream."""
@@ -376,8 +377,8 @@ class GradReducer:
             self._launch(b)
         self._next = len(self.buckets)
         self._defer(False)
-        for w in self._works:
-            w.wait()
+        for b in self.buckets:
+            self.wait_bucket(b["index"])
         self._works.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -120,8 +120,8 @@ class GraphedTrainStep:
         r = self.reducer
         for b in r.buckets:
             r._launch(b)
-        for w in r._works:
-            w.wait()
+        for b in r.buckets:
+            r.wait_bucket(b["index"])
         r._works.clear()
         if r.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(r.comm_stream)
