@@ -164,6 +164,8 @@ def main():
 
     def train_step(i):
         b = batches[i % len(batches)]
+        if (world > 1 or reducer._force) and not reducer.staged:
+            reducer.set_staged(True)    # eager N > 1: complete buckets are all-reduced at the model's flush points, beside the rest of backward
         reducer.zero_grad()
         loss = net(b["raw"], b["input"], b["label"], b["depth"], mode="loss")["loss"]
         (scaler.scale(loss) if scaler is not None else loss).backward()

@@ -92,6 +92,13 @@ class GradReducer:
             seen.add(id(p))
             params.append((n, p))
         params.reverse()  # readiness order ≈ reverse registration order
+        # ... refined by the model where registration order and backward order disagree: dgtd.nn.cod registers the texture diffuser
+        # (ConvNeXt trunk) BEFORE the prompt decoders but AFTER the PVT stages, while in the backward pass the PVT stages and the prompt
+        # decoders finish first and the ConvNeXt trunk last.  Buckets go out strictly in order, so without this every PVT bucket would
+        # queue behind the ConvNeXt buckets.  (Stable sort: reverse registration order inside a rank; identical on every rank.)
+        rank_of = getattr(module, "grad_readiness_rank", None)
+        if callable(rank_of):
+            params.sort(key=lambda np_: rank_of(np_[0]))
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
         for n, p in params:
@@ -116,6 +123,7 @@ class GradReducer:
         self._cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self._cuda and self.overlap) else None
         self._works, self._next = [], 0
+        self.staged = False
         for b in self.buckets:
             for leaf in b["leaves"]:
                 leaf.register_post_accumulate_grad_hook(self._make_hook(b))
@@ -226,7 +234,7 @@ class GradReducer:
             nat = _native.ops()
             if nat is not None:
                 if on:      # one gradient tensor for all calls of a shared weight needs a single flush, after the whole backward pass
-                    nat.set_shared_deferral(not self.overlap)
+                    nat.set_shared_deferral(not self.overlap or self.staged)   # staged: flushes happen only at the model's flush points
                 nat.set_deferred(on)
 
     def _flush_deferred(self) -> None:
@@ -241,9 +249,27 @@ class GradReducer:
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
                 bucket["ready"] = True
-                if self.overlap:
+                if self.overlap and not self.staged:
                     self._advance()
         return hook
+
+    # ------------------------------------------------------------------ staged overlap
+    def set_staged(self, on: bool) -> None:
+        """Staged overlap: the hooks only mark buckets ready; at the model's FLUSH POINTS (ops/_native.py: the gradient of the diffuser
+        embedding, the gradient of every ConvNeXt stage input) the parked weight-gradient work is flushed in whole per-stage batches,
+        every complete bucket is gathered and its all-reduce forked onto the side stream, where it runs beside the rest of the
+        backward pass.  ~95 % of the gradient bytes are deferred weight gradients, so gathering from the per-leaf hooks instead (the
+        plain ``overlap`` mode) has to flush early and chops those batches into per-bucket pieces (measured slower)."""
+        from ..ops import _native
+        self.staged = bool(on)
+        _native.FLUSH_POINT[0] = self.flush_point if on else None
+
+    def flush_point(self) -> None:
+        if not self.staged or self._next >= len(self.buckets):
+            return
+        if not self.buckets[self._next]["ready"]:
+            return                                 # nothing complete yet: keep the parked work for a bigger batch
+        self._advance()                            # _gather flushes first
 
     def _advance(self) -> None:
         """Collectives are issued in BUCKET ORDER on every rank: bucket i goes out only once buckets < i have.  A bucket whose

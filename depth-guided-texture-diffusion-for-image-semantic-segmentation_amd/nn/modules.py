@@ -328,6 +328,7 @@ class ShapePropEncoder(nn.Module):
                 cw, cb = wb(conv)
                 t = ops.linear(_patchify(norm(t), h, w, 2), cw.flatten(1), cb)
                 h, w = h // 2, w // 2
+            ops.mark_flush_point(t)            # backward: this stage (and everything after it) is done when this gradient arrives
             t4 = t.view(B, h, w, -1)
             with ops.block_run(self, i, len(self.stages[i]), t4) as run:     # identical blocks: their weight-gradient GEMMs batch
                 for j, blk in enumerate(self.stages[i]):
@@ -544,6 +545,7 @@ class PyramidVisionTransformerImpr(nn.Module):
         image = x
         embedding1, embedding3 = self.prompt_encoder(image, depth, x_hp=x_hp)
         embedding3 = embedding3.contiguous(memory_format=torch.channels_last)
+        ops.mark_flush_point(embedding3)       # backward: Hitnet decoder, all PVT blocks and the prompt decoders are done at this gradient
         if _USE["async_flush"] and embedding3.requires_grad and embedding3.is_cuda:
             # backward: when this gradient arrives, the Hitnet decoder, every PVT block and the prompt decoders are done and the whole
             # ConvNeXt trunk is still to go - their parked weight-gradient work (batched GEMMs, depthwise / 3x3 weight gradients) starts
@@ -825,6 +827,19 @@ class cod(nn.Module):
         for i, m in enumerate(self._dp_layers):
             m.index, m.plan = i, self._dp_plan
         self.register_buffer("_dp_keep", torch.tensor([[1.0 - m.drop_prob] for m in self._dp_layers] or [[1.0]]), persistent=False)
+
+    @staticmethod
+    def grad_readiness_rank(name: str) -> int:
+        """Order in which parameter groups finish in the BACKWARD pass (dist.GradReducer buckets follow it): Hitnet decoder and heads,
+        then the PVT stages, then the prompt decoders, then the texture diffuser (ConvNeXt trunk, regressor, depth embedding) - the
+        diffuser is upstream of everything (cod.py:1455-1472) although it is registered between the PVT stages and the prompt decoders."""
+        if not name.startswith("hitnet.backbone."):
+            return 0
+        if name.startswith("hitnet.backbone.prompt_encoder."):
+            return 3
+        if name.startswith("hitnet.backbone.prompt_decoder."):
+            return 2
+        return 1
 
     def _draw_drop_path(self, batch: int) -> None:
         """All stochastic-depth masks of the step in one shot: [n_layers, B] of {0, 1/keep} (cod.py:935, :1102 per layer)."""

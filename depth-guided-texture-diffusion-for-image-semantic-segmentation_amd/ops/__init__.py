@@ -2,7 +2,7 @@
 (twig/ops/functions/ms_deform_attn_func.py:19-46): forward saves its inputs, backward is
 once_differentiable and returns one gradient per input."""
 from . import _native  # noqa: F401
-from ._native import NO_RUN, block_run  # noqa: F401
+from ._native import NO_RUN, block_run, mark_flush_point  # noqa: F401
 from .layernorm import layer_norm, layer_norm_fork  # noqa: F401
 from .attention import sra_attention  # noqa: F401
 from .diffuser import diffuser_state, diffuse_tail  # noqa: F401

@@ -100,3 +100,25 @@ class _NoRun:
 
 
 NO_RUN = _NoRun()
+
+
+# ------------------------------------------------------------------------------------------------ flush points
+# Places in the BACKWARD pass where every gradient produced so far is complete and no shared deferral is half-way: when the gradient of
+# the texture-diffuser embedding arrives (Hitnet decoder, all PVT blocks and the prompt decoders are done) and when the gradient of a
+# ConvNeXt stage's input arrives (that stage is done).  A gradient reducer in staged mode (dist.GradReducer.staged) registers its
+# flush_point() here: it flushes the deferred weight-gradient work parked so far (whole per-stage batches), gathers every complete
+# bucket and forks its all-reduce, which then runs beside the rest of the backward pass.
+FLUSH_POINT = [None]
+
+
+def flush_point_hook(grad):
+    fn = FLUSH_POINT[0]
+    if fn is not None:
+        fn()
+    return None
+
+
+def mark_flush_point(t: torch.Tensor) -> None:
+    """Call in the forward pass on a tensor whose gradient marks a flush point (no-op unless a staged reducer is listening)."""
+    if FLUSH_POINT[0] is not None and t.requires_grad:
+        t.register_hook(flush_point_hook)

@@ -49,11 +49,12 @@ class _no_cat:
 class GraphedTrainStep:
     """``comm`` decides how the gradient all-reduce of an N > 1 job meets the captured step:
 
-    * ``"fused"``: ONE graph with the collectives captured inside it.  After the backward pass (one flush of the deferred weight-gradient
-      phase: ~95 % of the gradient bytes are weight gradients that only exist after it) every bucket is gathered and its all-reduce is
-      forked onto the reducer's side stream at once; AdamW then walks the buckets and waits for each bucket's own all-reduce only.  In
-      the replayed graph the RCCL kernels of bucket i run beside the gather of buckets > i and the optimizer of buckets < i.  Needs a
-      backend whose collectives are stream-ordered and capturable (RCCL).
+    * ``"fused"``: ONE graph with the collectives captured inside it, STAGED overlap: at the model's flush points in the backward pass
+      (gradient of the diffuser embedding = Hitnet decoder + PVT + prompt decoders done; gradient of each ConvNeXt stage input) the
+      weight-gradient work parked so far is flushed in whole per-stage batches, every complete bucket is gathered and its all-reduce
+      forked onto the reducer's side stream, where it runs beside the rest of the backward pass; the remaining buckets follow after
+      the backward pass, and AdamW walks the buckets waiting for each bucket's own all-reduce only.  Needs a backend whose
+      collectives are stream-ordered and capturable (RCCL).
     * ``"hooks"``: ONE graph as well, but the autograd hooks gather a bucket when its last gradient arrives and fork its collective
       during the backward pass (the eager overlap mode, recorded).  The literal "overlap with backward" - and measured SLOWER: a gather
       inside the backward pass must flush the parked weight-gradient work early, which chops the batched launches of the deferred
@@ -104,9 +105,17 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         s = self.static
-        self.reducer.zero_grad()
-        loss = self.net(None, s["input"], s["label"], s["depth"], mode="loss", x_hp=s["x_hp"])["loss"]
-        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        r = self.reducer
+        staged = self.mode == "fused"
+        if staged:
+            r.set_staged(True)            # buckets complete at the model's flush points are all-reduced beside the rest of backward
+        try:
+            r.zero_grad()
+            loss = self.net(None, s["input"], s["label"], s["depth"], mode="loss", x_hp=s["x_hp"])["loss"]
+            (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        finally:
+            if staged:
+                r.set_staged(False)
         return loss
 
     def _gather_all(self) -> None:
@@ -190,9 +199,9 @@ class GraphedTrainStep:
         r = self.reducer
         overlap = r.overlap
         self._overlap_before = overlap
-        # hooks: the autograd hooks gather + fork the collectives (eager overlap mode, recorded); otherwise hooks only count and
-        # gather / launch are explicit in _one_step
-        r.overlap = overlap if self.mode == "hooks" else False
+        # hooks: the autograd hooks gather + fork the collectives (eager overlap mode, recorded); fused: they only mark buckets ready and
+        # the flush points gather / launch (reducer.set_staged); otherwise they only count and gather / launch are explicit in _one_step
+        r.overlap = overlap if self.mode in ("hooks", "fused") else False
         try:
             s = self.stream
             s.wait_stream(torch.cuda.current_stream())
