@@ -248,6 +248,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+    if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
+        # random init at the config's lr 5e-4 (meant for pretrained weights) can diverge on the synthetic batches; NaN is not JSON
+        print(f"[bench] final loss is not finite ({final_loss})", file=sys.stderr, flush=True)
+        final_loss = None
 
     # ---- instrumented pass: per-call HIP-event timing inside libdgtd.so (not part of `value`)
     roofline, kernels, attention, entries = None, [], [], []
@@ -372,7 +376,7 @@ def main():
                        "mode": args.mode, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": graphed is not None, "graph_mode": graph_mode,
                        "allreduce_payload": (None if not (world > 1 or reducer._force) else ("16-bit working dtype + fp32 rest" if reducer.comm16 else "fp32")),
-                       "final_loss": round(final_loss, 4) if train else None,
+                       "final_loss": round(final_loss, 4) if (train and final_loss is not None) else None,
                        "host_enqueue_ms_per_step": round(1e3 * host / args.steps, 2),
                        "reference_algorithmic_tflops": round(imgs / dt * flops_per_img / 1e12, 2),
                        "loss_scale": scaler.get_scale() if scaler is not None else None},
