@@ -66,13 +66,15 @@ struct DkdvSmem {
 };
 
 constexpr int KGROUP = 128;   // keys per dK/dV workgroup (4 waves x 32)
+constexpr int64_t DKDV_MAX_WGS = 1024;                       // workgroups that may carry a partial slab
+constexpr int64_t DKDV_SLAB_BYTES = DKDV_MAX_WGS * 65536;    // 64 MB
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const T* __restrict__ q, const T* __restrict__ kv,
                                                             const T* __restrict__ dout, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dkv,
                                                             int N, int Nkv, int heads, int kgroups, float scale, int qch,
-                                                            int use_atomics) {
+                                                            int64_t slab_stride) {
   typedef T bf16_t;                                  // T = bf16_t or f16_t
   typedef typename Vec16<T>::type bf16x8;
   __shared__ __attribute__((aligned(16))) DkdvSmem<T> sm;
@@ -183,18 +185,36 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dkdv_bf16(const T* __restrict_
       for (int i = 0; i < 16; ++i) {
         const int kk = ktile0 + mfma_row(i, h);
         if (kk < Nkv) {
-          float* p = dkv + ((size_t)b * Nkv + kk) * 2 * C + hd * 64 + nb * 32 + r;   // lanes r: 128-B contiguous segments
-          if (use_atomics) { atomicAdd(p, dk[nb][i]); atomicAdd(p + C, dv[nb][i]); }
-          else { p[0] = dk[nb][i]; p[C] = dv[nb][i]; }   // this workgroup swept every query: the sum is complete
+          // lanes r: 128-B contiguous segments.  slab_stride == 0: this workgroup swept every query, the sum is complete and goes
+          // straight to dkv; otherwise the query chunks write PLAIN partial slabs [chunk][B][Nkv][2C] that dkdv_reduce_kernel sums
+          // (no fp32 atomics: 512 workgroups x 64 KB of atomic adds cost ~25 us of a 63 us launch at the chip-wide atomic rate)
+          float* p = dkv + (size_t)blockIdx.x * slab_stride + ((size_t)b * Nkv + kk) * 2 * C + hd * 64 + nb * 32 + r;
+          p[0] = dk[nb][i];
+          p[C] = dv[nb][i];
         }
       }
   }
 }
 
+// dkv[i] = sum over the query chunks of slab[c][i]  (float4 body; n is a multiple of 4: 2C = 128 heads floats per key)
+__global__ __launch_bounds__(256) void dkdv_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dkv, int64_t n4, int chunks,
+                                                          int64_t stride4) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+  f32x4* o4 = reinterpret_cast<f32x4*>(dkv);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 acc = s4[i];
+    for (int c = 1; c < chunks; ++c) {
+      const f32x4 v = s4[i + (int64_t)c * stride4];
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    o4[i] = acc;
+  }
+}
+
 template <typename T, int KCH>
-__global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const T* __restrict__ q, const T* __restrict__ kv,
+__global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const T* __restrict__ q, const T* __restrict__ kv, const T* __restrict__ o,
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, T* __restrict__ dq,
+                                                          float* __restrict__ delta, T* __restrict__ dq,
                                                           int N, int Nkv, int heads, float scale, int qtw) {
   typedef T bf16_t;
   typedef typename Vec16<T>::type bf16x8;
@@ -225,7 +245,20 @@ __global__ __launch_bounds__(256, 2) void sra_bwd_dq_bf16(const T* __restrict__ 
     }
     const size_t so = ((size_t)b * heads + hd) * N + q0 + r;
     const float l2 = qok ? lse[so] * LOG2E : INFINITY;
-    const float dl = qok ? delta[so] : 0.f;
+    // delta = rowsum(dO * O) of this lane's query: the lane pair (h = 0, 1) holds the dO row already (gf), O is read the same way; the
+    // separate delta launch and its second pass over dO / O are gone.  Written out for the dK/dV kernel, which runs after this one.
+    float dl = 0.f;
+    if (qok) {
+      const size_t off = ((size_t)b * N + q0 + r) * C + hd * 64 + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + off + 16 * s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)gf[s][j];
+      }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (qok && h == 0) delta[so] = dl;
     f32x16 dqa[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqa[0][i] = 0.f; dqa[1][i] = 0.f; }
@@ -483,8 +516,11 @@ __global__ __launch_bounds__(512) void sra_bwd_f32(const float* __restrict__ q, 
 
 }  // namespace
 
-// delta [B,h,N] fp32
-extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) { return (int64_t)B * N * heads * sizeof(float); }
+// workspace = delta [B,h,N] fp32 (256-byte aligned) + the dK/dV partial slabs of the query chunks (16-bit paths; bounded: every
+// workgroup owns 128 keys x 64 channels x {K, V} x 4 B = 64 KB of one slab and at most ~2 x 512 workgroups carry a slab)
+extern "C" int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads) {
+  return (((int64_t)B * N * heads * 4 + 255) / 256) * 256 + DKDV_SLAB_BYTES;
+}
 
 extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse,
                                  void* dq, float* dkv_f32, void* workspace, int B, int N, int Nkv, int heads, float scale,
@@ -497,36 +533,45 @@ extern "C" int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out,
   const int64_t items = (int64_t)B * N * heads;
   const int qtiles = (int)cdiv(N, 32);
   if (DGTD_IS_HALF(dt)) {
-    DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((attn_delta_kernel<T_>), dim3((unsigned)cdiv(items * 8, 256)), dim3(256), 0, st, (const T_*)out, (const T_*)dout, delta, B, N, heads));
-    DGTD_CHECK_LAUNCH("attn_delta");
-    // dK/dV: workgroup = 128 keys (4 waves) x a chunk of query tiles.  Keys are split across workgroups; queries are split
-    // only as far as needed to put ~1 workgroup on every CU, because every extra query chunk costs one more fp32-atomic flush
-    // of the whole dK/dV (the chip-wide atomic rate is ~1.3 TB/s).  With a single chunk the result is stored plainly.
+    // (1) dQ, forward-shaped launch; computes delta = rowsum(dO * O) on the way and writes it for (2)
+    {
+      int qtw = 1;
+      while (qtw < 8 && cdiv(N, 128) * B * heads / (qtw * 2) >= 512) qtw *= 2;
+      dim3 grid((unsigned)cdiv(N, 128 * qtw), heads, B);
+      if (Nkv <= 64) {
+        constexpr int KCH = 64;
+        DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
+                           (const T_*)out, (const T_*)dout, lse, delta, (T_*)dq, N, Nkv, heads, scale, qtw));
+      } else {
+        constexpr int KCH = 256;
+        DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
+                           (const T_*)out, (const T_*)dout, lse, delta, (T_*)dq, N, Nkv, heads, scale, qtw));
+      }
+      DGTD_CHECK_LAUNCH("sra_attn_bwd_dq");
+    }
+    // (2) dK/dV: workgroup = 128 keys (4 waves) x a chunk of query tiles.  Keys are split across workgroups; queries are split as far as
+    // needed to put ~2 workgroups on every CU.  With a single chunk the result is stored plainly into dkv; with several, every chunk
+    // writes a plain partial slab and ONE reduce launch sums them (was: fp32 atomics into a caller-zeroed buffer).
     const int kgroups = (int)cdiv(Nkv, KGROUP);
     DGTD_REQUIRE((int64_t)heads * kgroups <= 65535, "sra_attn_bwd: heads*kgroups too large for the grid");
-    // 512 workgroups = two waves per SIMD: 75 -> 63 us at stage 1 (B=8, N=16384); 1024 loses again to the extra atomic flushes (81 us)
     static const int64_t wg_env = getenv("DGTD_DKDV_WGS") ? atol(getenv("DGTD_DKDV_WGS")) : 0;
     const int64_t cols = (int64_t)B * heads * kgroups;
-    // (measured per stage of config 2: 512 helps the long-query stages 1-2, costs 8-9 us at stages 3-4 where it only adds flushes)
-    const int64_t wg_target = wg_env ? wg_env : (cols <= 32 ? 512 : 256);
-    const int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(wg_target, cols)));
+    const int64_t wg_target = wg_env ? std::min<int64_t>(wg_env, DKDV_MAX_WGS) : (cols <= 32 ? 512 : 256);
+    int nq = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(wg_target, cols)));
+    const int64_t dkv_elems = (int64_t)B * Nkv * 2 * heads * 64;
+    float* slab = (float*)((char*)workspace + (((int64_t)B * N * heads * 4 + 255) / 256) * 256);
+    while (nq > 1 && (int64_t)nq * dkv_elems * 4 > DKDV_SLAB_BYTES) --nq;      // the slabs must fit the workspace
     const int qch = (int)cdiv(qtiles, nq);
     const int nqc = (int)cdiv(qtiles, qch);
     DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL(sra_bwd_dkdv_bf16<T_>, dim3(nqc, heads * kgroups, B), dim3(256), 0, st, (const T_*)q, (const T_*)kv,
-                       (const T_*)dout, lse, (const float*)delta, dkv_f32, N, Nkv, heads, kgroups, scale, qch, nqc > 1 ? 1 : 0));
+                       (const T_*)dout, lse, (const float*)delta, nqc > 1 ? slab : dkv_f32, N, Nkv, heads, kgroups, scale, qch,
+                       nqc > 1 ? dkv_elems : (int64_t)0));
     DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv");
-    // dQ: forward-shaped launch
-    int qtw = 1;
-    while (qtw < 8 && cdiv(N, 128) * B * heads / (qtw * 2) >= 512) qtw *= 2;
-    dim3 grid((unsigned)cdiv(N, 128 * qtw), heads, B);
-    if (Nkv <= 64) {
-      constexpr int KCH = 64;
-      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
-                         (const T_*)dout, lse, (const float*)delta, (T_*)dq, N, Nkv, heads, scale, qtw));
-    } else {
-      constexpr int KCH = 256;
-      DGTD_DISPATCH_HALF(dt, hipLaunchKernelGGL((sra_bwd_dq_bf16<T_, KCH>), grid, dim3(256), (size_t)2 * KCH * 72 * 2, st, (const T_*)q, (const T_*)kv,
-                         (const T_*)dout, lse, (const float*)delta, (T_*)dq, N, Nkv, heads, scale, qtw));
+    if (nqc > 1) {
+      const int64_t n4 = dkv_elems / 4;
+      hipLaunchKernelGGL(dkdv_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 2048)), dim3(256), 0, st, (const float*)slab, dkv_f32, n4, nqc,
+                         n4);
+      DGTD_CHECK_LAUNCH("sra_attn_bwd_dkdv_reduce");
     }
   } else {
     hipLaunchKernelGGL((attn_delta_kernel<float>), dim3((unsigned)cdiv(items * 16, 256)), dim3(256), 0, st, (const float*)out, (const float*)dout, delta, B, N, heads);

@@ -690,7 +690,8 @@ struct SraAttnFn : public torch::autograd::Function<SraAttnFn> {
     const int ra = role_of(ctx->saved_data["hint"], 0), rb = role_of(ctx->saved_data["hint"], 1);
     const bool ar = hint.group >= 0 && deferring();
     Tensor dq = (ar && ra >= 0) ? arena_slot(hint, ROLE_DY + ra, q.sizes(), q.options()) : at::empty_like(q);
-    Tensor dkv = at::zeros(kv.sizes(), kv.options().dtype(at::kFloat));
+    // 16-bit paths overwrite every element (plain stores or the slab reduce); the fp32 kernel accumulates with atomics into zeros
+    Tensor dkv = is16(q.scalar_type()) ? at::empty(kv.sizes(), kv.options().dtype(at::kFloat)) : at::zeros(kv.sizes(), kv.options().dtype(at::kFloat));
     Tensor ws = at::empty({dgtd_sra_attn_bwd_workspace((int)B, (int)N, (int)heads)}, q.options().dtype(at::kByte));
     check(dgtd_sra_attn_bwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dq.data_ptr(),
                             dkv.data_ptr<float>(), ws.data_ptr(), (int)B, (int)N, (int)Nkv, (int)heads, (float)scale, code(q), stream()),

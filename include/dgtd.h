@@ -74,8 +74,10 @@ int dgtd_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma
  * lse [B, heads, N] fp32      = log-sum-exp of the scaled scores (saved for the backward)       */
 int dgtd_sra_attn_fwd(const void* q, const void* kv, void* out, float* lse,
                       int B, int N, int Nkv, int heads, float scale, dgtd_dtype dt, dgtd_stream s);
-/* dq [B,N,C] (dt);  dkv_f32 [B,Nkv,2C] fp32, must be ZEROED by the caller (atomically accumulated).
- * workspace: dgtd_sra_attn_bwd_workspace(B,N,heads) bytes (holds delta = rowsum(dO*O)).          */
+/* dq [B,N,C] (dt);  dkv_f32 [B,Nkv,2C] fp32.  DGTD_F32: must be ZEROED by the caller (atomically accumulated).  DGTD_BF16 / DGTD_F16:
+ * every element is overwritten (the query chunks of the key-stationary dK/dV kernel write plain partial slabs into the workspace and
+ * one reduce launch sums them; no atomics), so the result is bit-reproducible and the buffer needs no initialisation.
+ * workspace: dgtd_sra_attn_bwd_workspace(B,N,heads) bytes = delta = rowsum(dO*O) (computed inside the dQ kernel) + 64 MB of slabs.   */
 int64_t dgtd_sra_attn_bwd_workspace(int B, int N, int heads);
 int dgtd_sra_attn_bwd(const void* q, const void* kv, const void* out, const void* dout,
                       const float* lse, void* dq, float* dkv_f32, void* workspace,

@@ -7,6 +7,6 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/attn_tmp/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
-    if "sra_" in r["Name"] or "attn_delta" in r["Name"]:
+    if "sra_" in r["Name"] or "attn_delta" in r["Name"] or "dkdv_reduce" in r["Name"]:
         print(f"{r['Name'][:60]:60s} avg {float(r['AverageNs'])/1e3:7.1f} us  min {float(r['MinNs'])/1e3:7.1f} us  calls {r['Calls']}")
 PY
