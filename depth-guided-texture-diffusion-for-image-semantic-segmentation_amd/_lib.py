@@ -86,6 +86,7 @@ SIGNATURES = {
     "dgtd_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_supported": (_i, [_i, _i, _i, _i]),
     "dgtd_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_conv3x3_fwd_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_flip": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dgtd_conv3x3_wgrad_workspace": (_i64, [_i, _i, _i, _i, _i, _i]),
     "dgtd_conv3x3_wgrad_batched_workspace": (_i64, [_i, _i, _i, _i, _i, _i]),

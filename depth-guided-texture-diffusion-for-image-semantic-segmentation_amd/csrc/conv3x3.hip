@@ -26,6 +26,14 @@ __device__ __forceinline__ typename Vec16<T>::type zero8() {
   return v;
 }
 
+// Extra epilogue operands of conv3x3_fwd_kernel (dgtd_conv3x3_fwd_ex): everything the Hitnet CAB needs around its two convolutions
+// without a separate elementwise launch.  All tensors share y's layout [Z][B][H][W][Co].
+//   act 0: none   1: ReLU   2: PReLU forward  - y2 (optional) receives the pre-activation, y = pre > 0 ? pre : slope * pre
+//   act 3: PReLU backward - the convolution output is the gradient w.r.t. the PReLU OUTPUT; ref = the saved pre-activation:
+//          y = ref > 0 ? v : slope * v, and sum(v * ref over ref <= 0) is added atomically to *sgrad (one add per workgroup)
+//   add: y += add (the gradient of a skip connection that forks off the convolution's input), applied last
+struct ConvEpi { const void* add; const void* ref; void* y2; const float* slope; float* sgrad; int act; };
+
 template <typename T>
 __device__ __forceinline__ typename Vec16<T>::type load_masked(const T* __restrict__ src, const T* __restrict__ mask, size_t o) {
   typedef typename Vec16<T>::type V8;
@@ -49,7 +57,7 @@ template <typename T, int CI, int NT, int MT, int TWX>
 __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ mask,
                                                           const T* __restrict__ w, const T* __restrict__ bias,
                                                           T* __restrict__ y, int H, int W, int Co_full, int relu, int tiles_w,
-                                                          long x_zs, long w_zs, long y_zs, int nsplit) {
+                                                          long x_zs, long w_zs, long y_zs, int nsplit, ConvEpi epi) {
   constexpr int G = CI / 8, RW = 32 / TWX, TH = 4 * MT * RW, LW = TWX + 2, LP = (TH + 2) * LW;
   constexpr int COP = NT * 32, GP = G | 1, WSZ = COP * GP, NWR = (COP * G + 255) / 256;
   constexpr int WB = ((size_t)G * LP + 2 * WSZ) * 16 <= 65536 ? 2 : 1;   // double-buffer the kernel slices when LDS allows
@@ -147,27 +155,58 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const T* __restrict__ 
 
   // epilogue: lane holds pixel l31 of each m-tile; registers 4q..4q+3 = output channels 8q + 4*half + {0..3}
   const bf16_t* bz = bias ? bias + (size_t)z * Co_full + co_base : nullptr;
-  bf16_t* yb = y + (size_t)z * y_zs + img * Co_full + co_base;
+  const size_t ybase = (size_t)z * y_zs + img * Co_full + co_base;
+  bf16_t* yb = y + ybase;
+  const bf16_t* addb = epi.add ? (const bf16_t*)epi.add + ybase : nullptr;
+  const bf16_t* refb = epi.ref ? (const bf16_t*)epi.ref + ybase : nullptr;
+  bf16_t* y2b = epi.y2 ? (bf16_t*)epi.y2 + ybase : nullptr;
+  const int act = relu ? 1 : epi.act;
+  const float slope = (act >= 2) ? epi.slope[0] : 0.f;
+  float sg = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int h = h0 + (wave * MT + mt) * RW + pr, ww = w0 + pc;
     if (h >= H || ww >= W) continue;
-    bf16_t* yp = yb + ((size_t)h * W + ww) * Co_full;
+    const size_t po = ((size_t)h * W + ww) * Co_full;
+    bf16_t* yp = yb + po;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = nt * 32 + 8 * q + 4 * half;
         if (co >= Co) continue;
-        bf16x4 o;
+        bf16x4 o, rv, av;
+        if (act == 3) rv = *reinterpret_cast<const bf16x4*>(refb + po + co);
+        if (addb) av = *reinterpret_cast<const bf16x4*>(addb + po + co);
+        if (act == 2 && y2b) {
+          bf16x4 pre;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = (bf16_t)(acc[mt][nt][4 * q + e] + (bz ? (float)bz[co + e] : 0.f));
+          *reinterpret_cast<bf16x4*>(y2b + po + co) = pre;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[mt][nt][4 * q + e] + (bz ? (float)bz[co + e] : 0.f);
-          if (relu) v = fmaxf(v, 0.f);
+          if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 2) { v = (float)(bf16_t)v; v = v > 0.f ? v : slope * v; }           // PReLU of the ROUNDED pre-activation (what y2 holds)
+          else if (act == 3) {
+            const float r = (float)rv[e];
+            v = (float)(bf16_t)v;                                                               // the gradient tensor the unfused path stored
+            if (!(r > 0.f)) { sg += v * r; v *= slope; }
+          }
+          if (addb) v += (float)av[e];
           o[e] = (bf16_t)v;
         }
         *reinterpret_cast<bf16x4*>(yp + co) = o;
       }
+  }
+  if (act == 3 && epi.sgrad) {      // slope gradient: one atomic per workgroup (uniform branch; the LDS tiles are dead here)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    sg = wave_sum(sg);
+    if (lane == 0) red[wave] = sg;
+    __syncthreads();
+    if (tid == 0) atomicAdd(epi.sgrad, red[0] + red[1] + red[2] + red[3]);
   }
 }
 
@@ -373,7 +412,7 @@ inline FwdGeom fwd_geom(int Z, int B, int H, int W, int Ci) {
 
 template <typename T, int CI, int NT, int MT, int TWX>
 int launch_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co, int relu,
-               int shared_x, hipStream_t st, int nsplit = 1) {
+               int shared_x, hipStream_t st, const ConvEpi& epi, int nsplit = 1) {
   constexpr int RW = 32 / TWX, TH = 4 * MT * RW, LP = (TH + 2) * (TWX + 2), G = CI / 8, WSZ = NT * 32 * (G | 1);
   constexpr size_t lds = ((size_t)G * LP + ((((size_t)G * LP + 2 * WSZ) * 16 <= 65536) ? 2 : 1) * WSZ) * 16;
   static_assert(lds <= 65536, "halo tile + kernel slices exceed 64 KB of LDS");
@@ -381,27 +420,27 @@ int launch_fwd(const void* x, const void* mask, const void* w, const void* bias,
   const long plane = (long)B * H * W;
   hipLaunchKernelGGL((conv3x3_fwd_kernel<T, CI, NT, MT, TWX>), dim3(tiles_w * tiles_h, B, Z * nsplit), dim3(256), lds, st, (const T*)x,
                      (const T*)mask, (const T*)w, (const T*)bias, (T*)y, H, W, Co, relu, tiles_w,
-                     shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co, nsplit);
+                     shared_x ? 0L : plane * CI, (long)Co * 9 * CI, plane * Co, nsplit, epi);
   DGTD_CHECK_LAUNCH("conv3x3_fwd");
   return 0;
 }
 
 template <typename T, int CI, int NT>
 int dispatch_fwd_geom(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Co,
-                      int relu, int shared_x, hipStream_t st) {
+                      int relu, int shared_x, hipStream_t st, const ConvEpi& epi) {
   const FwdGeom g = fwd_geom(Z, B, H, W, CI);
   if constexpr (NT > 1) {   // fewer than 2 workgroups per CU: one workgroup per 32-channel output tile
     const long wgs = (long)Z * B * cdiv(H, 4 * (32 / g.twx)) * cdiv(W, g.twx);
     static const bool split_on = !(getenv("DGTD_CONV3X3_SPLIT") && getenv("DGTD_CONV3X3_SPLIT")[0] == '0');
     if (split_on && wgs < 512) {
-      if (g.twx == 16) return launch_fwd<T, CI, 1, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, NT);
-      return launch_fwd<T, CI, 1, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, NT);
+      if (g.twx == 16) return launch_fwd<T, CI, 1, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi, NT);
+      return launch_fwd<T, CI, 1, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi, NT);
     }
   }
-  if (g.twx == 16) return launch_fwd<T, CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
-  if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<T, CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
-  if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<T, CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st); }
-  return launch_fwd<T, CI, NT, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st);
+  if (g.twx == 16) return launch_fwd<T, CI, NT, 1, 16>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi);
+  if constexpr (CI <= 32) { if (g.mt == 4) return launch_fwd<T, CI, NT, 4, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi); }
+  if constexpr (CI <= 64) { if (g.mt >= 2) return launch_fwd<T, CI, NT, 2, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi); }
+  return launch_fwd<T, CI, NT, 1, 32>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi);
 }
 
 bool supported(int Ci, int Co) {
@@ -482,11 +521,12 @@ inline int wgrad_splits(int Z, int B, int H, int W, int Ci, int Co) {
 
 extern "C" int dgtd_conv3x3_supported(int Ci, int Co, int H, int W) { return supported(Ci, Co) && H >= 1 && W >= 16 && W % 16 == 0; }
 
-extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
-                                int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s) {
+static int conv3x3_fwd_impl(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W, int Ci, int Co,
+                            int relu, int shared_x, dgtd_dtype dt, dgtd_stream s, const ConvEpi& epi) {
   // roofline label: 18 Ci Co flop per pixel over 2 (Ci + Co) bytes; above the ridge (2.5 PF / 8 TB/s = 312 flop/B; 96 -> 96: 432) the
   // call is priced against the MFMA peak, below it against HBM
-  const double conv_bytes = 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co);
+  const int extra = (epi.add ? 1 : 0) + (epi.ref ? 1 : 0) + (epi.y2 ? 1 : 0);
+  const double conv_bytes = 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co * (1 + extra));
   const double conv_flops = 18.0 * Z * B * H * W * (double)Ci * Co;
   const bool conv_mfma = conv_flops > 312.5 * conv_bytes;
   DGTD_PROF(s, conv_mfma ? DGTD_MFMA : DGTD_HBM, conv_mfma ? conv_flops : conv_bytes, "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
@@ -494,15 +534,29 @@ extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, 
   DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_fwd: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);
   DGTD_REQUIRE(!(shared_x && mask), "conv3x3_fwd: a mask needs its own input per convolution");
+  DGTD_REQUIRE(epi.act >= 0 && epi.act <= 3 && !(relu && epi.act > 1), "conv3x3_fwd: bad activation %d", epi.act);
+  DGTD_REQUIRE(epi.act < 2 || epi.slope, "conv3x3_fwd: PReLU needs the slope");
+  DGTD_REQUIRE(epi.act != 3 || epi.ref, "conv3x3_fwd: the PReLU backward epilogue needs the saved pre-activation");
   hipStream_t st = (hipStream_t)s;
   const int nt = (int)cdiv(Co, 32);
-#define DGTD_CONV_CASE(CI_, NT_) if (Ci == CI_ && nt == NT_) DGTD_DISPATCH_HALF(dt, return (dispatch_fwd_geom<T_, CI_, NT_>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st)));
+#define DGTD_CONV_CASE(CI_, NT_) if (Ci == CI_ && nt == NT_) DGTD_DISPATCH_HALF(dt, return (dispatch_fwd_geom<T_, CI_, NT_>(x, mask, w, bias, y, Z, B, H, W, Co, relu, shared_x, st, epi)));
   DGTD_CONV_CASE(24, 1) DGTD_CONV_CASE(24, 2) DGTD_CONV_CASE(24, 3)
   DGTD_CONV_CASE(32, 1) DGTD_CONV_CASE(32, 2) DGTD_CONV_CASE(32, 3)
   DGTD_CONV_CASE(64, 1) DGTD_CONV_CASE(64, 2) DGTD_CONV_CASE(64, 3)
   DGTD_CONV_CASE(96, 1) DGTD_CONV_CASE(96, 2) DGTD_CONV_CASE(96, 3)
 #undef DGTD_CONV_CASE
   DGTD_FAIL(2, "conv3x3_fwd: no kernel for Ci=%d Co=%d", Ci, Co);
+}
+
+extern "C" int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
+                                int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s) {
+  return conv3x3_fwd_impl(x, mask, w, bias, y, Z, B, H, W, Ci, Co, relu, shared_x, dt, s, ConvEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+}
+
+extern "C" int dgtd_conv3x3_fwd_ex(const void* x, const void* mask, const void* w, const void* bias, void* y, void* y2, const void* add, const void* ref,
+                                   const float* slope, float* slope_grad, int Z, int B, int H, int W, int Ci, int Co, int act, int shared_x,
+                                   dgtd_dtype dt, dgtd_stream s) {
+  return conv3x3_fwd_impl(x, mask, w, bias, y, Z, B, H, W, Ci, Co, 0, shared_x, dt, s, ConvEpi{add, ref, y2, slope, slope_grad, act});
 }
 
 extern "C" int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s) {

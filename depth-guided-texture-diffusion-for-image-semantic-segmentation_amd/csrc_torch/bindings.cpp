@@ -1527,6 +1527,134 @@ struct BilinearFn : public torch::autograd::Function<BilinearFn> {
   }
 };
 
+// ------------------------------------------------------------------------------------------------ Hitnet CAB as ONE node
+// out = x + gate(res) * res, res = conv3x3(PReLU(conv3x3(x, w0)), w1), gate = sigmoid(W2 relu(W1 mean(res)))   (CAB, cod.py:436-451)
+// Forward 4 launches (conv + PReLU epilogue writing pre-activation and activation; conv; pooled sums; gate apply + residual) instead
+// of 5; backward: gate backward, input-gradient convolution of w1 with the PReLU backward (and the slope gradient) in its epilogue,
+// input-gradient convolution of w0 with the skip gradient added in its epilogue - no PReLU launches and no autograd add for the
+// fork of x.  Weight gradients: the deferred batched launch of §4b (shared destination for the 4 calls of a module) or immediate.
+inline Tensor flipped_weight(const Tensor& w, int Z, int Co, int Ci) {
+  Tensor wt;
+  const bool cache = deferring() && Z == 1;
+  if (cache) {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    auto it = g_conv_flip.find(w.data_ptr());
+    if (it != g_conv_flip.end()) wt = it->second;
+  }
+  if (!wt.defined()) {
+    wt = at::empty({Z, Ci, 3, 3, Co}, w.options());
+    check(dgtd_conv3x3_flip(w.data_ptr(), wt.data_ptr(), Z, Co, Ci, stream()), "dgtd_conv3x3_flip");
+    if (cache) {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      g_conv_flip.emplace(w.data_ptr(), wt);
+    }
+  }
+  return wt;
+}
+
+struct CabFn : public torch::autograd::Function<CabFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& w0_, const Tensor& w1_, const Tensor& a, const Tensor& cw1,
+                        const Tensor& cw2) {
+    Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor w0 = w0_.contiguous(at::MemoryFormat::ChannelsLast), w1 = w1_.contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(x.is_cuda() && is16(x.scalar_type()) && w0.scalar_type() == x.scalar_type() && w1.scalar_type() == x.scalar_type() && a.numel() == 1,
+                "dgtd cab: bf16 / fp16 tensors of one dtype on the HIP device and a single PReLU slope");
+    const int B = (int)x.size(0), C = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
+    const int64_t R = cw1.size(0), HW = (int64_t)H * W;
+    Tensor a32 = f32(a);
+    Tensor t0 = at::empty_like(x), t1 = at::empty_like(x), res = at::empty_like(x), out = at::empty_like(x);
+    check(dgtd_conv3x3_fwd_ex(x.data_ptr(), nullptr, w0.data_ptr(), nullptr, t1.data_ptr(), t0.data_ptr(), nullptr, nullptr, a32.data_ptr<float>(), nullptr,
+                              1, B, H, W, C, C, 2, 0, code(x), stream()), "dgtd_conv3x3_fwd_ex (conv + PReLU)");
+    check(dgtd_conv3x3_fwd(t1.data_ptr(), nullptr, w1.data_ptr(), nullptr, res.data_ptr(), 1, B, H, W, C, C, 0, 0, code(x), stream()), "dgtd_conv3x3_fwd");
+    Tensor w1f = f32(cw1.reshape({R, C})), w2f = f32(cw2.reshape({C, R}));
+    Tensor stats = at::empty({2 * B * C + B * R + 64 * B * C}, x.options().dtype(at::kFloat));
+    check(dgtd_ca_gate_fwd(res.data_ptr(), x.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), out.data_ptr(), stats.data_ptr<float>(), B, (int)HW,
+                           C, (int)R, code(x), stream()), "dgtd_ca_gate_fwd");
+    ctx->save_for_backward({x, w0, w1, t0, t1, res, a32, w1f, w2f, stats});
+    const ConvKey key{B, H, W, C, C, (int)code(x)};
+    ctx->saved_data["defer0"] = conv_register(w0_, w0, key);
+    ctx->saved_data["defer1"] = conv_register(w1_, w1, key);
+    note_leaf(ctx, "leaf_w0", w0_); note_leaf(ctx, "leaf_w1", w1_); note_leaf(ctx, "leaf_a", a);
+    ctx->saved_data["meta"] = std::vector<int64_t>{st_id(a), st_id(cw1), (a.requires_grad() && !a.grad_fn()) ? (int64_t)(intptr_t)a.data_ptr() : (int64_t)0,
+                                                   x_.requires_grad()};
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w0 = saved[1], &w1 = saved[2], &t0 = saved[3], &t1 = saved[4], &res = saved[5], &a32 = saved[6], &w1f = saved[7],
+                 &w2f = saved[8], &stats = saved[9];
+    const auto m = ctx->saved_data["meta"].toIntVector();
+    const auto a_dt = (at::ScalarType)m[0], cw_dt = (at::ScalarType)m[1];
+    const void* akey = (const void*)(intptr_t)m[2];
+    const int B = (int)x.size(0), C = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
+    const int64_t R = w1f.size(0), HW = (int64_t)H * W;
+    Tensor g = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    // (1) through the gate: dres, the CA weight gradients; the skip gradient is g itself
+    Tensor dres = at::empty_like(x);
+    Tensor small = at::empty({2 * R * C + B * C + 64 * B * C + B * 2 * R * C}, x.options().dtype(at::kFloat));
+    float* sp = small.data_ptr<float>();
+    check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), sp,
+                           sp + R * C, sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd");
+    Tensor dcw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1}), dcw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});
+    if (cw_dt != at::kFloat) { dcw1 = dcw1.to(cw_dt); dcw2 = dcw2.to(cw_dt); }
+    // (2) slope accumulator: the ONE PReLU of the decoder (cod.py:686) is shared by every CAB - one fp32 scalar per step (shared deferral),
+    //     or a private one for this call
+    bool share = akey && deferring() && g_shared_ok.load(std::memory_order_relaxed);
+    if (share) {
+      bool have;
+      queue_final_flush();
+      { std::lock_guard<std::mutex> lk(g_pending_mu); have = g_prelu_acc.count(akey) > 0; }
+      if (!have && leaf_has_grad(ctx, "leaf_a")) share = false;
+    }
+    Tensor acc, da;
+    if (share) {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      auto it = g_prelu_acc.find(akey);
+      if (it == g_prelu_acc.end()) {
+        acc = at::zeros({1}, x.options().dtype(at::kFloat));
+        da = at::empty({1}, x.options().dtype(a_dt));
+        g_prelu_acc.emplace(akey, acc);
+        g_pending.push_back(PendingReduce{dgtd_reduce_entry{acc.data_ptr<float>(), 1, 1, nullptr, 0, da.data_ptr(), (int32_t)code(da), 0, 0, nullptr}, acc});
+      } else {
+        acc = it->second;             // later calls add into the same scalar and hand autograd nothing
+      }
+    } else {
+      acc = at::zeros({1}, x.options().dtype(at::kFloat));
+    }
+    // (3) input gradient of the second convolution, taken through the PReLU in its epilogue (dt0 = gradient w.r.t. the pre-activation)
+    Tensor dt0 = at::empty_like(x);
+    Tensor wt1 = flipped_weight(w1, 1, C, C);
+    check(dgtd_conv3x3_fwd_ex(dres.data_ptr(), nullptr, wt1.data_ptr(), nullptr, dt0.data_ptr(), nullptr, nullptr, t0.data_ptr(), a32.data_ptr<float>(),
+                              acc.data_ptr<float>(), 1, B, H, W, C, C, 3, 0, code(x), stream()), "dgtd_conv3x3_fwd_ex (input gradient through PReLU)");
+    if (!share) da = a_dt == at::kFloat ? acc : acc.to(a_dt);
+    // (4) input gradient of the first convolution + the skip gradient
+    Tensor dx;
+    if (m[3]) {
+      dx = at::empty_like(x);
+      Tensor wt0 = flipped_weight(w0, 1, C, C);
+      check(dgtd_conv3x3_fwd_ex(dt0.data_ptr(), nullptr, wt0.data_ptr(), nullptr, dx.data_ptr(), nullptr, g.data_ptr(), nullptr, nullptr, nullptr, 1, B, H, W,
+                                C, C, 0, 0, code(x), stream()), "dgtd_conv3x3_fwd_ex (input gradient + skip)");
+    }
+    // (5) weight gradients
+    const ConvKey key{B, H, W, C, C, (int)code(x)};
+    auto wgrad = [&](const char* dkey, const char* lkey, const Tensor& xin, const Tensor& dy, const Tensor& w) {
+      Tensor dw, db;
+      const bool parked = ctx->saved_data[dkey].toBool() && deferring() && (conv_dest_exists(w) || !leaf_has_grad(ctx, lkey)) &&
+                          conv_park(xin, dy, Tensor(), w, key, false, dw, db);
+      if (!parked) {
+        dw = at::empty_like(w);
+        Tensor ws = at::empty({dgtd_conv3x3_wgrad_workspace(1, B, H, W, C, C)}, x.options().dtype(at::kByte));
+        check(dgtd_conv3x3_wgrad(xin.data_ptr(), dy.data_ptr(), nullptr, dw.data_ptr(), nullptr, ws.data_ptr(), 1, B, H, W, C, C, 0, code(x), stream()),
+              "dgtd_conv3x3_wgrad");
+      }
+      return dw;
+    };
+    Tensor dw1 = wgrad("defer1", "leaf_w1", t1, dres, w1);
+    Tensor dw0 = wgrad("defer0", "leaf_w0", x, dt0, w0);
+    return {dx, dw0, dw1, da, dcw1, dcw2};
+  }
+};
+
 Tensor layer_norm(const Tensor& x, const Tensor& w, const Tensor& b, double eps) { return LayerNormFn::apply(x, w, b, eps); }
 std::tuple<Tensor, Tensor> layer_norm_fork(const Tensor& x, const Tensor& w, const Tensor& b, double eps) {
   auto r = LayerNormForkFn::apply(x, w, b, eps);
@@ -1552,6 +1680,9 @@ Tensor mlp_residual(const Tensor& v, const Tensor& w1, const Tensor& b1, const T
   return MlpResidualFn::apply(v, w1, b1, w2, b2, x, s, gamma, dt_code);
 }
 bool gemm_ok(int64_t M, int64_t N, int64_t K, int64_t dt_code) { return own_ok(from_code(dt_code), M, N, K); }
+Tensor cab(const Tensor& x, const Tensor& w0, const Tensor& w1, const Tensor& a, const Tensor& cw1, const Tensor& cw2) {
+  return CabFn::apply(x, w0, w1, a, cw1, cw2);
+}
 Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3Fn::apply(x, w, b, relu); }
 Tensor conv3x3_cl(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, bool relu) { return Conv3x3ClFn::apply(x, w, b, relu); }
 Tensor prelu(const Tensor& x, const Tensor& a) { return PReLUFn::apply(x, a); }
@@ -1572,6 +1703,7 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("linear_residual(Tensor h, Tensor weight, Tensor bias, Tensor x, Tensor? s, Tensor? gamma, int dtype_code) -> Tensor", &linear_residual);
   m.def("mlp_residual(Tensor v, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor x, Tensor? s, Tensor? gamma, int dtype_code) -> Tensor", &mlp_residual);
   m.def("gemm_ok(int M, int N, int K, int dtype_code) -> bool", &gemm_ok);
+  m.def("cab(Tensor x, Tensor w0, Tensor w1, Tensor a, Tensor cw1, Tensor cw2) -> Tensor", &cab);
   m.def("conv3x3(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3);
   m.def("conv3x3_cl(Tensor x, Tensor weight, Tensor? bias, bool relu) -> Tensor", &conv3x3_cl);
   m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);

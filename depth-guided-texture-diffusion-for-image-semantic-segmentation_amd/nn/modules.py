@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused", "async_flush")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused", "async_flush", "cab_node")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -666,6 +666,10 @@ class CAB(nn.Module):
             w0, w1 = wb(c0)[0], wb(c1)[0]
             if (_USE["conv3x3"] and c0.bias is None and c1.bias is None and w0.dtype == x.dtype
                     and ops.conv3x3_ops.supported(x, x.shape[1], x.shape[1], x.shape[2], x.shape[3])):
+                if _USE["cab_node"]:             # the whole CAB as one node: PReLU (+ backward) and the skip gradient in conv epilogues
+                    out = ops.cab(x, w0, w1, act.weight, du[0].weight, du[2].weight)
+                    if out is not None:
+                        return out
                 res = ops.conv3x3(ops.prelu(ops.conv3x3(x, w0), act.weight), w1)      # NHWC bf16 MFMA kernels
             else:
                 res = c1(ops.prelu(c0(x), act.weight))

@@ -224,3 +224,14 @@ class _UnstackFn(Function):
 
 def unstack(x: torch.Tensor):
     return _UnstackFn.apply(x) if x.is_cuda else tuple(x.unbind(0))
+
+
+def cab(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, a: torch.Tensor, cw1: torch.Tensor, cw2: torch.Tensor):
+    """The whole CAB (cod.py:436-451) - conv3x3 -> PReLU -> conv3x3 -> channel-attention gate -> + x - as ONE autograd node of the C++
+    binding layer (csrc_torch/bindings.cpp CabFn): the PReLU and its backward ride in the convolutions' epilogues
+    (dgtd_conv3x3_fwd_ex), the skip gradient is added inside the first convolution's input-gradient launch.  None when the node is not
+    available (Python bindings, profiler attached): the caller composes the separate ops."""
+    nat = _native.ops()
+    if nat is None or not x.is_cuda or not hasattr(nat, "cab"):
+        return None
+    return nat.cab(x, w0, w1, a, cw1, cw2)

@@ -276,6 +276,15 @@ int dgtd_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, i
 int dgtd_conv3x3_supported(int Ci, int Co, int H, int W);
 int dgtd_conv3x3_fwd(const void* x, const void* mask, const void* w, const void* bias, void* y, int Z, int B, int H, int W,
                      int Ci, int Co, int relu, int shared_x, dgtd_dtype dt, dgtd_stream s);
+/* The same convolution with the epilogues a Hitnet CAB needs around its two convolutions (cod.py:441-451), so that the PReLU, its
+ * backward and the skip-connection gradient are not separate launches.  y2 / add / ref have y's layout [Z,B,H,W,Co]; any may be NULL.
+ *   act 0 none, 1 ReLU;  act 2 PReLU forward: y2 (optional) = pre-activation, y = pre > 0 ? pre : slope[0] * pre  (act = body[1], cod.py:444);
+ *   act 3 PReLU backward: the convolution output v is the gradient w.r.t. the PReLU OUTPUT, ref = the saved pre-activation:
+ *         y = ref > 0 ? v : slope[0] * v and sum(v * ref | ref <= 0) is added atomically to slope_grad[0] (one add per workgroup; optional);
+ *   add: y += add, applied last (the gradient of the skip connection `+ x` of cod.py:451 that forks off the convolution's input).     */
+int dgtd_conv3x3_fwd_ex(const void* x, const void* mask, const void* w, const void* bias, void* y, void* y2, const void* add,
+                        const void* ref, const float* slope, float* slope_grad, int Z, int B, int H, int W, int Ci, int Co, int act,
+                        int shared_x, dgtd_dtype dt, dgtd_stream s);
 /* wt [Z,Ci,3,3,Co] = w [Z,Co,3,3,Ci] transposed, taps flipped (any 2-byte dtype).                                                                */
 int dgtd_conv3x3_flip(const void* w, void* wt, int Z, int Co, int Ci, dgtd_stream s);
 /* dw [Z,Co,3,3,Ci] and db [Z,Co] (or NULL) of dtype dt, OVERWRITTEN; dy is masked like x above (mask = forward output, or NULL).

@@ -871,3 +871,89 @@ def test_mlp_residual_fused_node(dgtd, rows, C, dtype, with_s):
     for n, a, b_ in zip(names, got, rg):
         scale = math.sqrt(rows) if n in ("dW1", "db1", "dW2", "db2", "dgamma") else 1.0
         torch.testing.assert_close(a.float(), b_, atol=tol * scale, rtol=tol, msg=lambda m, n=n: f"{n}: {m}")
+
+
+# ---------------------------------------------------------------------------------------------- CAB: conv3x3 epilogues + the one-node form
+@pytest.mark.parametrize("C,S", [(32, 16), (64, 32), (96, 64)])
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_conv3x3_fwd_ex_epilogues(dgtd, C, S, half):
+    """dgtd_conv3x3_fwd_ex through the C ABI: PReLU forward (pre-activation + activation from one launch), PReLU backward in the
+    epilogue of an input-gradient convolution (+ the slope gradient) and the skip-gradient add, against fp32 torch (cod.py:441-451)."""
+    L = dgtd._lib
+    code, st = L.dtype_code(torch.empty(1, dtype=half)), L.stream_ptr()
+    B = 2
+    x = _rand(B, S, S, C, seed=1).to(half)                                   # NHWC
+    w = (_rand(C, 3, 3, C, seed=2) * 0.05).to(half)                          # O,H,W,I
+    slope = torch.tensor([0.25], device="cuda")
+    xr, wr = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
+    pre_ref = F.conv2d(xr, wr, padding=1).permute(0, 2, 3, 1)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    L.call("dgtd_conv3x3_fwd_ex", x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), y2.data_ptr(), None, None, slope.data_ptr(), None,
+           1, B, S, S, C, C, 2, 0, code, st)
+    torch.testing.assert_close(y2.float(), pre_ref, atol=3e-2, rtol=3e-2)
+    want = torch.where(y2.float() > 0, y2.float(), 0.25 * y2.float())
+    torch.testing.assert_close(y.float(), want, atol=1e-2, rtol=1e-2)         # PReLU of the stored pre-activation
+    # act 3 + add: v = conv(x, w); out = (ref > 0 ? v : slope v) + add; sgrad += sum(v * ref | ref <= 0)
+    ref = _rand(B, S, S, C, seed=3).to(half)
+    add = _rand(B, S, S, C, seed=4).to(half)
+    sg = torch.zeros(1, device="cuda")
+    out = torch.empty_like(x)
+    L.call("dgtd_conv3x3_fwd_ex", x.data_ptr(), None, w.data_ptr(), None, out.data_ptr(), None, add.data_ptr(), ref.data_ptr(), slope.data_ptr(),
+           sg.data_ptr(), 1, B, S, S, C, C, 3, 0, code, st)
+    v = pre_ref.to(half).float()
+    want = torch.where(ref.float() > 0, v, 0.25 * v) + add.float()
+    torch.testing.assert_close(out.float(), want, atol=4e-2, rtol=3e-2)
+    sg_ref = (v * ref.float())[ref.float() <= 0].sum()
+    assert abs(sg.item() - sg_ref.item()) <= 2e-2 * max(1.0, abs(sg_ref.item()), float((v * ref.float()).abs().sum()) ** 0.5)
+    # plain add only
+    L.call("dgtd_conv3x3_fwd_ex", x.data_ptr(), None, w.data_ptr(), None, out.data_ptr(), None, add.data_ptr(), None, None, None,
+           1, B, S, S, C, C, 0, 0, code, st)
+    torch.testing.assert_close(out.float(), pre_ref + add.float(), atol=4e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("C,S,red", [(32, 16, 4), (96, 64, 4)])
+@pytest.mark.parametrize("half", HALVES, ids=str)
+def test_cab_node_vs_composition_and_fp32(dgtd, C, S, red, half):
+    """The CAB as ONE C++ node (ops.cab) against the composition of the separate ops it replaces and against fp32 torch: output and the
+    gradients of the input, both convolution weights, the shared PReLU slope and the two channel-attention weights."""
+    M = dgtd.nn.modules
+    act = torch.nn.PReLU()
+    cab = dgtd.nn.CAB(C, 3, red, bias=False, act=act).cuda()
+    with torch.no_grad():
+        for p in cab.parameters():
+            p.copy_((0.2 * _rand(*p.shape, seed=int(p.numel()) % 97)).to(p.dtype))
+        act.weight.fill_(0.25)
+    x = _rand(2, C, S, S, seed=1).to(half).contiguous(memory_format=torch.channels_last)
+    g = _rand(2, C, S, S, seed=2).to(half).contiguous(memory_format=torch.channels_last)
+    params = [cab.body[0].weight, cab.body[2].weight, act.weight, cab.CA.conv_du[0].weight, cab.CA.conv_du[2].weight]
+
+    def run(node):
+        old = M._USE["cab_node"]
+        M._USE["cab_node"] = node
+        try:
+            xs = x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=half):
+                y = cab(xs)
+            grads = torch.autograd.grad(y, [xs] + params, g)
+        finally:
+            M._USE["cab_node"] = old
+        return y.detach().float(), [t.float() for t in grads]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    torch.testing.assert_close(y1, y0, atol=2e-2, rtol=2e-2)
+    names = ["dx", "dw0", "dw1", "da", "dcw1", "dcw2"]
+    for n, a, b_ in zip(names, g1, g0):
+        tol = 3e-2 * max(1.0, float(b_.abs().max()))
+        torch.testing.assert_close(a, b_, atol=tol, rtol=3e-2, msg=lambda m, n=n: f"node vs composition {n}: {m}")
+    # fp32 torch reference of the module's reference semantics (cod.py:436-451)
+    xr = x.float().requires_grad_()
+    pr = [p.detach().float().requires_grad_() for p in params]
+    t = F.conv2d(F.prelu(F.conv2d(xr, pr[0], padding=1), pr[2]), pr[1], padding=1)
+    gate = torch.sigmoid(F.conv2d(F.relu(F.conv2d(t.mean((2, 3), keepdim=True), pr[3])), pr[4]))
+    ref = t * gate + xr
+    gr = torch.autograd.grad(ref, [xr] + pr, g.float())
+    torch.testing.assert_close(y1, ref.detach(), atol=6e-2, rtol=5e-2)
+    for n, a, b_ in zip(names, g1, gr):
+        tol = 6e-2 * max(1.0, float(b_.abs().max()))
+        torch.testing.assert_close(a, b_, atol=tol, rtol=6e-2, msg=lambda m, n=n: f"node vs fp32 {n}: {m}")
