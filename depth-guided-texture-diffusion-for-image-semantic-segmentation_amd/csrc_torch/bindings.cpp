@@ -277,6 +277,11 @@ static std::vector<PendingConv> g_pending_conv;
 // (first call: zeroed here and handed to autograd through a parked 1x1 "reduction" that converts it; later calls return nothing)
 static std::map<const void*, Tensor> g_prelu_acc;
 static std::map<const void*, Tensor> g_conv_flip;        // weight -> its flipped copy, valid for one step (cleared at every flush)
+// the two 1x1 weights of a CAB's channel-attention MLP (cod.py:420-425) get one gradient per call of the module (4 per step): every call
+// writes its { dw1 | dw2 } row into a per-module buffer, the first call hands autograd the (unwritten) sums, the flush adds the rows up
+struct CaAcc { Tensor buf; int count, rc; void* out1; void* out2; };
+static std::map<const void*, CaAcc> g_ca_acc;            // key: the first weight's data pointer
+constexpr int CA_MAX_CALLS = 8;
 
 // Deferrals that hand ONE gradient tensor to autograd for several calls are only sound when nothing is flushed between the first and
 // the last of those calls: the reducer switches them off when it gathers buckets from inside the backward pass (eager overlap mode).
@@ -404,7 +409,7 @@ void flush_deferred_async() {
   if (!on) return;
   {
     std::lock_guard<std::mutex> lk(g_pending_mu);
-    if (g_pending.empty() && g_pending_dw.empty() && g_pending_gemm.empty() && g_pending_conv.empty()) return;
+    if (g_pending.empty() && g_pending_dw.empty() && g_pending_gemm.empty() && g_pending_conv.empty() && g_ca_acc.empty()) return;
   }
   join_async();                                     // one side branch at a time
   const auto cur = c10::hip::getCurrentHIPStream();
@@ -453,6 +458,16 @@ static void flush_deferred_impl() {
     std::lock_guard<std::mutex> lk(g_pending_mu);
     todo.swap(g_pending);
     dws.swap(g_pending_dw);
+  }
+  std::map<const void*, CaAcc> cas;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    cas.swap(g_ca_acc);
+  }
+  for (auto& kv : cas) {
+    CaAcc& a = kv.second;
+    keep_for_side(a.buf);
+    todo.push_back(PendingReduce{dgtd_reduce_entry{a.buf.data_ptr<float>(), a.count, 2 * a.rc, (float*)a.out1, a.rc, a.out2, (int32_t)DGTD_F32, 0, 0, nullptr}, a.buf});
   }
   g_flushed += (int64_t)(gemms.size() + todo.size() + dws.size());
   for (auto& p : todo) keep_for_side(p.ws);
@@ -556,6 +571,7 @@ void set_deferred(bool on) {
     g_conv_seen.clear();
     g_prelu_acc.clear();
     g_conv_flip.clear();
+    g_ca_acc.clear();
     g_uses.clear();
     g_slot_used.clear();
   } else {
@@ -568,7 +584,7 @@ void set_deferred(bool on) {
 int64_t flushed_reductions() { return g_flushed.load(); }    // cumulative number of parked entries that flush_deferred() has served
 int64_t pending_reductions() {
   std::lock_guard<std::mutex> lk(g_pending_mu);
-  return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size() + g_pending_conv.size());
+  return (int64_t)(g_pending.size() + g_pending_dw.size() + g_pending_gemm.size() + g_pending_conv.size() + g_ca_acc.size());
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -1575,8 +1591,10 @@ struct CabFn : public torch::autograd::Function<CabFn> {
     ctx->saved_data["defer0"] = conv_register(w0_, w0, key);
     ctx->saved_data["defer1"] = conv_register(w1_, w1, key);
     note_leaf(ctx, "leaf_w0", w0_); note_leaf(ctx, "leaf_w1", w1_); note_leaf(ctx, "leaf_a", a);
+    note_leaf(ctx, "leaf_cw1", cw1); note_leaf(ctx, "leaf_cw2", cw2);
     ctx->saved_data["meta"] = std::vector<int64_t>{st_id(a), st_id(cw1), (a.requires_grad() && !a.grad_fn()) ? (int64_t)(intptr_t)a.data_ptr() : (int64_t)0,
-                                                   x_.requires_grad()};
+                                                   x_.requires_grad(), (is_leaf(cw1) && is_leaf(cw2) && cw2.scalar_type() == cw1.scalar_type())
+                                                                           ? (int64_t)(intptr_t)cw1.data_ptr() : (int64_t)0};
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list gr) {
@@ -1589,14 +1607,40 @@ struct CabFn : public torch::autograd::Function<CabFn> {
     const int B = (int)x.size(0), C = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
     const int64_t R = w1f.size(0), HW = (int64_t)H * W;
     Tensor g = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
-    // (1) through the gate: dres, the CA weight gradients; the skip gradient is g itself
+    // (1) through the gate: dres, the CA weight gradients; the skip gradient is g itself.  A module called several times per step (the
+    //     decoder iterations) writes one { dw1 | dw2 } row per call into its accumulator buffer; the first call hands autograd the sums
     Tensor dres = at::empty_like(x);
     Tensor small = at::empty({2 * R * C + B * C + 64 * B * C + B * 2 * R * C}, x.options().dtype(at::kFloat));
     float* sp = small.data_ptr<float>();
-    check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), sp,
-                           sp + R * C, sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd");
-    Tensor dcw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1}), dcw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});
-    if (cw_dt != at::kFloat) { dcw1 = dcw1.to(cw_dt); dcw2 = dcw2.to(cw_dt); }
+    float* row = sp;                                 // where this call's { dw1 | dw2 } go
+    Tensor dcw1, dcw2;
+    const void* ckey = (const void*)(intptr_t)m[4];
+    bool ca_shared = ckey && cw_dt == at::kFloat && deferring() && g_shared_ok.load(std::memory_order_relaxed);
+    if (ca_shared) {
+      queue_final_flush();
+      bool have;
+      { std::lock_guard<std::mutex> lk(g_pending_mu); have = g_ca_acc.count(ckey) > 0; }
+      if (!have && (leaf_has_grad(ctx, "leaf_cw1") || leaf_has_grad(ctx, "leaf_cw2"))) ca_shared = false;
+    }
+    if (ca_shared) {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      auto it = g_ca_acc.find(ckey);
+      if (it == g_ca_acc.end()) {
+        dcw1 = at::empty({R, C, 1, 1}, x.options().dtype(at::kFloat));
+        dcw2 = at::empty({C, R, 1, 1}, x.options().dtype(at::kFloat));
+        CaAcc acc{at::empty({CA_MAX_CALLS, 2 * R * C}, x.options().dtype(at::kFloat)), 0, (int)(R * C), dcw1.data_ptr(), dcw2.data_ptr()};
+        it = g_ca_acc.emplace(ckey, acc).first;
+      }
+      if (it->second.count < CA_MAX_CALLS) row = it->second.buf.data_ptr<float>() + (int64_t)(it->second.count++) * 2 * R * C;
+      else ca_shared = false;                        // more calls than rows: this one goes through autograd's own accumulation
+    }
+    check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), row,
+                           row + R * C, sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd");
+    if (!ca_shared) {
+      dcw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1});
+      dcw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});
+      if (cw_dt != at::kFloat) { dcw1 = dcw1.to(cw_dt); dcw2 = dcw2.to(cw_dt); }
+    }
     // (2) slope accumulator: the ONE PReLU of the decoder (cod.py:686) is shared by every CAB - one fp32 scalar per step (shared deferral),
     //     or a private one for this call
     bool share = akey && deferring() && g_shared_ok.load(std::memory_order_relaxed);
