@@ -529,7 +529,9 @@ static int conv3x3_fwd_impl(const void* x, const void* mask, const void* w, cons
   const double conv_bytes = 2.0 * B * H * W * ((shared_x ? 1.0 : (double)Z) * Ci * (mask ? 2 : 1) + (double)Z * Co * (1 + extra));
   const double conv_flops = 18.0 * Z * B * H * W * (double)Ci * Co;
   const bool conv_mfma = conv_flops > 312.5 * conv_bytes;
-  DGTD_PROF(s, conv_mfma ? DGTD_MFMA : DGTD_HBM, conv_mfma ? conv_flops : conv_bytes, "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]", Z, H, W, Ci, Co);
+  // the epilogue operands change the bytes (and with them the side of the ridge), so they are part of the key
+  DGTD_PROF(s, conv_mfma ? DGTD_MFMA : DGTD_HBM, conv_mfma ? conv_flops : conv_bytes, extra ? "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d,+%d]" : "dgtd_conv3x3_fwd[Z=%d,%dx%d,%d->%d]",
+            Z, H, W, Ci, Co, extra);
   DGTD_REQUIRE(Z > 0 && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad sizes");
   DGTD_REQUIRE(DGTD_IS_HALF(dt), "conv3x3_fwd: dtype %d (the kernel is bf16 / fp16 only)", (int)dt);
   DGTD_REQUIRE(dgtd_conv3x3_supported(Ci, Co, H, W), "conv3x3_fwd: unsupported geometry Ci=%d Co=%d H=%d W=%d", Ci, Co, H, W);

@@ -1521,6 +1521,110 @@ struct CAGateFn : public torch::autograd::Function<CAGateFn> {
   }
 };
 
+// SAM (cod.py:454-506) as one node: 2 launches forward, 2 backward (csrc/sam.hip)
+struct SamFn : public torch::autograd::Function<SamFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& xh_, const Tensor& xl_, const Tensor& w1, const Tensor& w2, const Tensor& v1,
+                        const Tensor& v2) {
+    Tensor xh = xh_.contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor xl = (xl_.scalar_type() == xh.scalar_type() ? xl_ : xl_.to(xh.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(xh.is_cuda() && xh.dim() == 4 && xl.sizes() == xh.sizes(), "dgtd sam: two 4-D maps of one shape on the HIP device");
+    const int64_t B = xh.size(0), C = xh.size(1), HW = xh.size(2) * xh.size(3), R = w1.size(0);
+    TORCH_CHECK(w1.numel() == R * C && w2.numel() == C * R && v1.numel() == R * C && v2.numel() == R, "dgtd sam: weight shapes");
+    Tensor w1f = f32(w1.reshape({R, C})), w2f = f32(w2.reshape({C, R})), v1f = f32(v1.reshape({R, C})), v2f = f32(v2.reshape({R}));
+    Tensor stats = at::empty({dgtd_sam_stats_floats((int)B, (int)C, (int)R)}, xh.options().dtype(at::kFloat));
+    Tensor out = at::empty_like(xh);
+    check(dgtd_sam_fwd(xh.data_ptr(), xl.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), v1f.data_ptr<float>(), v2f.data_ptr<float>(),
+                       out.data_ptr(), stats.data_ptr<float>(), (int)B, (int)HW, (int)C, (int)R, code(xh), stream()), "dgtd_sam_fwd");
+    ctx->save_for_backward({xh, xl, w1f, w2f, v1f, v2f, stats});
+    ctx->saved_data["w_dt"] = std::vector<int64_t>{st_id(w1), st_id(w2), st_id(v1), st_id(v2)};
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &xh = saved[0], &xl = saved[1], &w1f = saved[2], &w2f = saved[3], &v1f = saved[4], &v2f = saved[5], &stats = saved[6];
+    const int64_t B = xh.size(0), C = xh.size(1), HW = xh.size(2) * xh.size(3), R = w1f.size(0);
+    Tensor g = (gr[0].scalar_type() == xh.scalar_type() ? gr[0] : gr[0].to(xh.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dxh = at::empty_like(xh), dxl = at::empty_like(xh);
+    Tensor dw = at::empty({3 * R * C + R}, xh.options().dtype(at::kFloat));
+    Tensor scratch = at::empty({dgtd_sam_scratch_floats((int)B, (int)C)}, xh.options().dtype(at::kFloat));
+    check(dgtd_sam_bwd(g.data_ptr(), xh.data_ptr(), xl.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), v1f.data_ptr<float>(),
+                       v2f.data_ptr<float>(), stats.data_ptr<float>(), dxh.data_ptr(), dxl.data_ptr(), dw.data_ptr<float>(), scratch.data_ptr<float>(),
+                       (int)B, (int)HW, (int)C, (int)R, code(xh), stream()), "dgtd_sam_bwd");
+    const auto dts = ctx->saved_data["w_dt"].toIntVector();
+    auto as = [&](Tensor t, int i) { return st_of(dts[i]) == at::kFloat ? t : t.to(st_of(dts[i])); };
+    return {dxh, dxl, as(dw.narrow(0, 0, R * C).view({R, C}), 0), as(dw.narrow(0, R * C, R * C).view({C, R}), 1),
+            as(dw.narrow(0, 2 * R * C, R * C).view({R, C}), 2), as(dw.narrow(0, 3 * R * C, R).view({1, R}), 3)};
+  }
+};
+
+// nn.BatchNorm2d of BasicConv2d (cod.py:359, :366) as one node: 2 launches each way (csrc/batchnorm.hip), the running statistics and
+// num_batches_tracked moved inside the second forward launch.  A module applied several times per step (compress_out, compress_out2,
+// conv4 inside the decoder loop, cod.py:757-789) writes one { dgamma | dbeta } row per call; the flush adds the rows up (as for the CAB's
+// channel-attention weights) so autograd sees one gradient per parameter per step.
+struct BatchNormFn : public torch::autograd::Function<BatchNormFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_, const Tensor& gamma, const Tensor& beta, Tensor running_mean, Tensor running_var,
+                        Tensor num_batches, bool training, double momentum, double eps) {
+    Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(x.is_cuda() && x.dim() == 4, "dgtd batch_norm takes a 4-D map on the HIP device");
+    const int64_t C = x.size(1), N = x.numel() / C;
+    TORCH_CHECK(gamma.scalar_type() == at::kFloat && beta.scalar_type() == at::kFloat && running_mean.scalar_type() == at::kFloat &&
+                running_var.scalar_type() == at::kFloat && num_batches.scalar_type() == at::kLong && gamma.is_contiguous() && beta.is_contiguous() &&
+                running_mean.is_contiguous() && running_var.is_contiguous(), "dgtd batch_norm: fp32 parameters / statistics and an int64 counter");
+    Tensor y = at::empty_like(x);
+    Tensor save = at::empty({training ? 2 * C : 0}, x.options().dtype(at::kFloat));
+    Tensor scratch = at::empty({training ? dgtd_batchnorm_scratch((int)C) : 0}, x.options().dtype(at::kFloat));
+    check(dgtd_batchnorm_fwd(x.data_ptr(), gamma.data_ptr<float>(), beta.data_ptr<float>(), running_mean.data_ptr<float>(), running_var.data_ptr<float>(),
+                             (long long*)num_batches.data_ptr<int64_t>(), y.data_ptr(), training ? save.data_ptr<float>() : nullptr,
+                             training ? scratch.data_ptr<float>() : nullptr, N, (int)C, (float)eps, (float)momentum, training ? 1 : 0, code(x), stream()),
+          "dgtd_batchnorm_fwd");
+    ctx->saved_data["training"] = training;
+    ctx->save_for_backward({x, gamma, save});
+    note_leaf(ctx, "leaf_g", gamma); note_leaf(ctx, "leaf_b", beta);
+    ctx->saved_data["key"] = (is_leaf(gamma) && is_leaf(beta)) ? (int64_t)(intptr_t)gamma.data_ptr() : (int64_t)0;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gr) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &gamma = saved[1], &save = saved[2];
+    TORCH_CHECK(ctx->saved_data["training"].toBool(), "dgtd batch_norm: the backward exists for training statistics only");
+    const int64_t C = x.size(1), N = x.numel() / C;
+    Tensor g = (gr[0].scalar_type() == x.scalar_type() ? gr[0] : gr[0].to(x.scalar_type())).contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dx = at::empty_like(x);
+    Tensor scratch = at::empty({dgtd_batchnorm_scratch((int)C)}, x.options().dtype(at::kFloat));
+    Tensor dg, db, own;
+    float* row = nullptr;
+    const void* key = (const void*)(intptr_t)ctx->saved_data["key"].toInt();
+    bool shared = key && deferring() && g_shared_ok.load(std::memory_order_relaxed);
+    if (shared) {
+      queue_final_flush();
+      bool have;
+      { std::lock_guard<std::mutex> lk(g_pending_mu); have = g_ca_acc.count(key) > 0; }
+      if (!have && (leaf_has_grad(ctx, "leaf_g") || leaf_has_grad(ctx, "leaf_b"))) shared = false;
+    }
+    if (shared) {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      auto it = g_ca_acc.find(key);
+      if (it == g_ca_acc.end()) {
+        dg = at::empty({C}, x.options().dtype(at::kFloat));
+        db = at::empty({C}, x.options().dtype(at::kFloat));
+        CaAcc acc{at::empty({CA_MAX_CALLS, 2 * C}, x.options().dtype(at::kFloat)), 0, (int)C, dg.data_ptr(), db.data_ptr()};
+        it = g_ca_acc.emplace(key, acc).first;
+      }
+      if (it->second.count < CA_MAX_CALLS) row = it->second.buf.data_ptr<float>() + (int64_t)(it->second.count++) * 2 * C;
+      else shared = false;
+    }
+    if (!shared) {
+      own = at::empty({2 * C}, x.options().dtype(at::kFloat));
+      row = own.data_ptr<float>();
+      dg = own.narrow(0, 0, C);
+      db = own.narrow(0, C, C);
+    }
+    check(dgtd_batchnorm_bwd(g.data_ptr(), x.data_ptr(), gamma.data_ptr<float>(), save.data_ptr<float>(), dx.data_ptr(), row, row + C,
+                             scratch.data_ptr<float>(), N, (int)C, code(x), stream()), "dgtd_batchnorm_bwd");
+    return {dx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
 struct BilinearFn : public torch::autograd::Function<BilinearFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_, int64_t Ho, int64_t Wo, bool align) {
     Tensor x = x_.contiguous(at::MemoryFormat::ChannelsLast);
@@ -1732,6 +1836,13 @@ Tensor conv3x3_cl(const Tensor& x, const Tensor& w, const c10::optional<Tensor>&
 Tensor prelu(const Tensor& x, const Tensor& a) { return PReLUFn::apply(x, a); }
 Tensor ca_gate(const Tensor& res, const Tensor& x, const Tensor& w1, const Tensor& w2) { return CAGateFn::apply(res, x, w1, w2); }
 Tensor bilinear_resize(const Tensor& x, int64_t oh, int64_t ow, bool align) { return BilinearFn::apply(x, oh, ow, align); }
+Tensor sam(const Tensor& xh, const Tensor& xl, const Tensor& w1, const Tensor& w2, const Tensor& v1, const Tensor& v2) {
+  return SamFn::apply(xh, xl, w1, w2, v1, v2);
+}
+Tensor batch_norm(const Tensor& x, const Tensor& gamma, const Tensor& beta, Tensor running_mean, Tensor running_var, Tensor num_batches, bool training,
+                  double momentum, double eps) {
+  return BatchNormFn::apply(x, gamma, beta, running_mean, running_var, num_batches, training, momentum, eps);
+}
 
 }  // namespace
 
@@ -1753,6 +1864,9 @@ TORCH_LIBRARY(dgtd, m) {
   m.def("prelu(Tensor x, Tensor a) -> Tensor", &prelu);
   m.def("ca_gate(Tensor res, Tensor x, Tensor w1, Tensor w2) -> Tensor", &ca_gate);
   m.def("bilinear_resize(Tensor x, int oh, int ow, bool align) -> Tensor", &bilinear_resize);
+  m.def("sam(Tensor xh, Tensor xl, Tensor w1, Tensor w2, Tensor v1, Tensor v2) -> Tensor", &sam);
+  m.def("batch_norm(Tensor x, Tensor weight, Tensor bias, Tensor(a!) running_mean, Tensor(b!) running_var, Tensor(c!) num_batches, bool training, "
+        "float momentum, float eps) -> Tensor", &batch_norm);
   m.def("set_deferred(bool on) -> ()", &set_deferred);
   m.def("flush_deferred() -> ()", &flush_deferred);
   m.def("flush_deferred_async() -> ()", &flush_deferred_async);

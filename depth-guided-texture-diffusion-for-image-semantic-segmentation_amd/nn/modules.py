@@ -19,7 +19,7 @@ from .. import ops
 
 LATENT = 24
 # A/B switches for tools/ and bench runs (default: every native path on)
-_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused", "async_flush", "cab_node")}
+_USE = {k: os.environ.get("DGTD_" + k.upper(), "1") != "0" for k in ("bilinear", "conv3x3", "cab_glue", "fused_linear", "ln_fork", "conv_gemm", "mlp_fused", "async_flush", "cab_node", "batchnorm", "sam_node")}
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -622,17 +622,23 @@ class BasicConv2d(nn.Module):
         self.bn = nn.BatchNorm2d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
+    def _bn(self, t):
+        """cod.py:366: the fused statistics + apply kernels (two launches each way) where they tile the map, torch's otherwise."""
+        if _USE["batchnorm"] and ops.batch_norm_supported(t, self.bn):
+            return ops.batch_norm(t, self.bn)
+        return self.bn(t)
+
     def forward(self, x):
         c = self.conv
         w = wb(c)[0]
         if (_USE["conv3x3"] and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
                 and w.dtype == x.dtype and ops.conv3x3_ops.supported(x, c.in_channels, c.out_channels, x.shape[2], x.shape[3])):
-            return self.bn(ops.conv3x3(x, w))        # conv4 (96 -> 32 at S/8, cod.py:713): NHWC bf16 MFMA kernel
+            return self._bn(ops.conv3x3(x, w))        # conv4 (96 -> 32 at S/8, cod.py:713): NHWC bf16 MFMA kernel
         if x.is_cuda and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0):
             # 1x1 conv == GEMM on tokens (cached hipBLASLt plan: a third of the host cost of a MIOpen call); views both ways
             Bc, _, Hc, Wc = x.shape
-            return self.bn(_tokens_to_nchw(ops.linear(_nchw_to_tokens(x), w.flatten(1), None), Hc, Wc))
-        return self.bn(self.conv(x))
+            return self._bn(_tokens_to_nchw(ops.linear(_nchw_to_tokens(x), w.flatten(1), None), Hc, Wc))
+        return self._bn(self.conv(x))
 
 
 class CALayer(nn.Module):
@@ -687,12 +693,16 @@ class SAM(nn.Module):
                                 Linear(ch_in // reduction, ch_in, bias=False), nn.Sigmoid())
         self.fc_wight = nn.Sequential(Linear(ch_in, ch_in // reduction, bias=False), nn.ReLU(inplace=True),
                                       Linear(ch_in // reduction, 1, bias=False), nn.Sigmoid())
+        for lin in (self.fc[0], self.fc[2], self.fc_wight[0], self.fc_wight[2]):
+            lin.keep_master = True                   # tiny fp32 MLPs inside ops.sam: no working copies
 
     def _gate(self, x):
-        y = x.mean((2, 3))
-        return x * self.fc(y)[:, :, None, None] * self.fc_wight(y)[:, :, None, None]
+        y = x.float().mean((2, 3))
+        return x * (self.fc(y) * self.fc_wight(y)).to(x.dtype)[:, :, None, None]
 
     def forward(self, x_h, x_l):
+        if _USE["sam_node"] and x_h.is_cuda and x_l.shape == x_h.shape and ops.sam_supported(x_h, self.fc[0].weight.shape[0]):
+            return ops.sam(x_h, x_l, self.fc[0].weight, self.fc[2].weight, self.fc_wight[0].weight, self.fc_wight[2].weight)
         return self._gate(x_h) + self._gate(x_l)
 
 

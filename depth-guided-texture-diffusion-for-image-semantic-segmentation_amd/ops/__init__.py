@@ -10,7 +10,8 @@ from .dwconv import dwconv_fork, dwconv_nhwc  # noqa: F401
 from .elementwise import colsum, linear, linear_gelu, linear_residual, mlp_residual, scale_residual  # noqa: F401
 from . import conv3x3 as conv3x3_ops  # noqa: F401
 from .conv3x3 import conv3x3, conv3x3_stack  # noqa: F401
-from .hitnet import bilinear_resize, ca_gate, cab, cat_channels, prelu, stack, unstack  # noqa: F401
+from .hitnet import (batch_norm, batch_norm_supported, bilinear_resize, ca_gate, cab, cat_channels, prelu, sam, sam_supported,  # noqa: F401
+                     stack, unstack)
 from .loss import seg_loss, ssim_value  # noqa: F401
 from .ms_deform_attn import MSDeformAttnFunction, ms_deform_attn  # noqa: F401
 from .conv_gemm import conv2d as conv2d_gemm, conv2d_tokens  # noqa: F401

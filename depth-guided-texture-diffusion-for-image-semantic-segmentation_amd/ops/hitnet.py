@@ -235,3 +235,107 @@ def cab(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, a: torch.Tensor, cw
     if nat is None or not x.is_cuda or not hasattr(nat, "cab"):
         return None
     return nat.cab(x, w0, w1, a, cw1, cw2)
+
+
+class _SamFn(Function):
+    @staticmethod
+    def forward(ctx, xh, xl, w1, w2, v1, v2):
+        _require_cuda(xh, xl)
+        xh, xl = _nhwc(xh), _nhwc(xl if xl.dtype == xh.dtype else xl.to(xh.dtype))
+        B, C, H, W = xh.shape
+        R = w1.shape[0]
+        ws = [w1.detach().reshape(R, C).float().contiguous(), w2.detach().reshape(C, R).float().contiguous(),
+              v1.detach().reshape(R, C).float().contiguous(), v2.detach().reshape(R).float().contiguous()]
+        stats = torch.empty(L.load().dgtd_sam_stats_floats(B, C, R), dtype=torch.float32, device=xh.device)
+        out = torch.empty_like(xh)
+        L.call("dgtd_sam_fwd", L.ptr(xh), L.ptr(xl), *(L.ptr(w) for w in ws), L.ptr(out), L.ptr(stats), B, H * W, C, R, L.dtype_code(xh),
+               L.stream_ptr(), algo=("hbm", 5 * xh.element_size() * xh.numel()), key=f"dgtd_sam_fwd[B={B},HW={H * W},C={C}]")
+        ctx.save_for_backward(xh, xl, *ws, stats)
+        ctx.meta = [(w.shape, w.dtype) for w in (w1, w2, v1, v2)]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xh, xl, w1f, w2f, v1f, v2f, stats = ctx.saved_tensors
+        B, C, H, W = xh.shape
+        R = w1f.shape[0]
+        g = _nhwc(g if g.dtype == xh.dtype else g.to(xh.dtype))
+        dxh, dxl = torch.empty_like(xh), torch.empty_like(xh)
+        dw = torch.empty(3 * R * C + R, dtype=torch.float32, device=xh.device)
+        scratch = torch.empty(L.load().dgtd_sam_scratch_floats(B, C), dtype=torch.float32, device=xh.device)
+        L.call("dgtd_sam_bwd", L.ptr(g), L.ptr(xh), L.ptr(xl), L.ptr(w1f), L.ptr(w2f), L.ptr(v1f), L.ptr(v2f), L.ptr(stats), L.ptr(dxh), L.ptr(dxl),
+               L.ptr(dw), L.ptr(scratch), B, H * W, C, R, L.dtype_code(xh), L.stream_ptr(),
+               algo=("hbm", 7 * xh.element_size() * xh.numel()), key=f"dgtd_sam_bwd[B={B},HW={H * W},C={C}]")
+        parts = (dw[:R * C], dw[R * C:2 * R * C], dw[2 * R * C:3 * R * C], dw[3 * R * C:])
+        return (dxh, dxl) + tuple(p.view(shape).to(dtype) for p, (shape, dtype) in zip(parts, ctx.meta))
+
+
+def sam_supported(x: torch.Tensor, R: int) -> bool:
+    return bool(x.is_cuda and x.ndim == 4 and
+                L.load().dgtd_sam_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], R, L.dtype_code(x)))
+
+
+def sam(xh: torch.Tensor, xl: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, v1: torch.Tensor, v2: torch.Tensor) -> torch.Tensor:
+    """SAM (cod.py:454-506): x_h * fc(mean x_h) * fc_wight(mean x_h) + x_l * fc(mean x_l) * fc_wight(mean x_l) in two launches
+    (backward: two).  w1 [R,C], w2 [C,R] = SAM.fc's bias-free Linear weights (cod.py:459-464); v1 [R,C], v2 [1,R] = SAM.fc_wight's
+    (cod.py:465-470)."""
+    nat = _native.ops()
+    if nat is not None and xh.is_cuda and hasattr(nat, "sam"):
+        return nat.sam(xh, xl, w1, w2, v1, v2)
+    return _SamFn.apply(xh, xl, w1, w2, v1, v2)
+
+
+class _BatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, training, momentum, eps):
+        _require_cuda(x)
+        x = _nhwc(x)
+        C = x.shape[1]
+        N = x.numel() // C
+        y = torch.empty_like(x)
+        save = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(L.load().dgtd_batchnorm_scratch(C), dtype=torch.float32, device=x.device)
+        L.call("dgtd_batchnorm_fwd", L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches), L.ptr(y),
+               L.ptr(save), L.ptr(scratch), N, C, float(eps), float(momentum), int(training), L.dtype_code(x), L.stream_ptr(),
+               algo=("hbm", (3 if training else 2) * x.element_size() * x.numel()),
+               key=f"dgtd_batchnorm_fwd[{'train' if training else 'eval'},N={N},C={C}]")
+        ctx.save_for_backward(x, gamma, save)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, gamma, save = ctx.saved_tensors
+        if not ctx.training:
+            raise L.DgtdError("dgtd batch_norm: the backward exists for training statistics only")
+        C = x.shape[1]
+        N = x.numel() // C
+        g = _nhwc(g if g.dtype == x.dtype else g.to(x.dtype))
+        dx = torch.empty_like(x)
+        d = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(L.load().dgtd_batchnorm_scratch(C), dtype=torch.float32, device=x.device)
+        L.call("dgtd_batchnorm_bwd", L.ptr(g), L.ptr(x), L.ptr(gamma), L.ptr(save), L.ptr(dx), d[:C].data_ptr(), d[C:].data_ptr(), L.ptr(scratch),
+               N, C, L.dtype_code(x), L.stream_ptr(), algo=("hbm", 5 * x.element_size() * x.numel()), key=f"dgtd_batchnorm_bwd[N={N},C={C}]")
+        return dx, d[:C], d[C:], None, None, None, None, None, None
+
+
+def batch_norm_supported(x: torch.Tensor, bn: torch.nn.BatchNorm2d) -> bool:
+    """True when ``bn(x)`` can run on the fused kernels: affine fp32 parameters, tracked statistics with a fixed momentum, training
+    mode or no gradient wanted, and a channel count the kernels tile (a power of two in [8, 128])."""
+    if not (x.is_cuda and x.ndim == 4 and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32):
+        return False
+    if not bn.training and torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        return False
+    return bool(L.load().dgtd_batchnorm_supported(x.numel() // x.shape[1], x.shape[1], L.dtype_code(x)))
+
+
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm2d) -> torch.Tensor:
+    """``bn(x)`` for the nn.BatchNorm2d of a BasicConv2d (cod.py:359, :366) on a channels_last map: two launches forward (the running
+    statistics and num_batches_tracked move inside the second), two backward.  Same state_dict entries, same update rule as torch's."""
+    args = (x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bool(bn.training), float(bn.momentum), float(bn.eps))
+    nat = _native.ops()
+    if nat is not None and hasattr(nat, "batch_norm"):
+        return nat.batch_norm(*args)
+    return _BatchNormFn.apply(*args)

@@ -258,6 +258,35 @@ int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const floa
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 
+/* SAM (twig/model/cod.py:454-506) over NHWC maps x_h, x_l [B,HW,C]: out = x_h G(x_h) + x_l G(x_l) with
+ * G(x)[b][c] = sigmoid(W2 relu(W1 y))[c] * sigmoid(V2 relu(V1 y)), y = mean_hw(x)[b]; W1 [R,C], W2 [C,R] = SAM.fc (cod.py:459-464),
+ * V1 [R,C], V2 [R] = SAM.fc_wight (cod.py:465-470), fp32.  C <= 128, R <= 32, 3 R C + R <= 1024.  stats fp32
+ * [dgtd_sam_stats_floats(B, C, R)] is written by the forward and read by the backward; nothing has to be zeroed (fixed-order sums).
+ * Backward: dxh, dxl [B,HW,C] and dw fp32 { dW1 [R,C] | dW2 [C,R] | dV1 [R,C] | dV2 [R] } overwritten; scratch fp32
+ * [dgtd_sam_scratch_floats(B, C)].                                                                                               */
+int dgtd_sam_supported(int B, int HW, int C, int R, dgtd_dtype dt);
+int64_t dgtd_sam_stats_floats(int B, int C, int R);
+int64_t dgtd_sam_scratch_floats(int B, int C);
+int dgtd_sam_fwd(const void* xh, const void* xl, const float* w1, const float* w2, const float* v1, const float* v2, void* out,
+                 float* stats, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
+int dgtd_sam_bwd(const void* g, const void* xh, const void* xl, const float* w1, const float* w2, const float* v1, const float* v2,
+                 const float* stats, void* dxh, void* dxl, float* dw, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt,
+                 dgtd_stream s);
+
+/* nn.BatchNorm2d of BasicConv2d (twig/model/cod.py:359, :366) over an NHWC map x [N = B*H*W, C]; gamma, beta, running statistics fp32
+ * (NULL gamma / beta = no affine).  training != 0: batch mean and biased variance per channel, y = (x - mean) rstd gamma + beta,
+ * running_mean / running_var (NULL = not tracked) moved by `momentum` with the unbiased variance, *num_batches += 1 (NULL = not
+ * counted), save fp32 [2*C] = { mean | rstd } for the backward, scratch fp32 [dgtd_batchnorm_scratch(C)].  training == 0: the affine
+ * map of the running statistics (save, scratch, num_batches unused).  C a power of two in [8, 128] (16-bit) / [4, 128] (fp32).
+ * Backward (training statistics): dx [N,C], dgamma [C], dbeta [C] (either may be NULL) overwritten; nothing to zero.            */
+int dgtd_batchnorm_supported(int64_t N, int C, dgtd_dtype dt);
+int64_t dgtd_batchnorm_scratch(int C);
+int dgtd_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       long long* num_batches, void* y, float* save, float* scratch, int64_t N, int C, float eps, float momentum,
+                       int training, dgtd_dtype dt, dgtd_stream s);
+int dgtd_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save, void* dx, float* dgamma, float* dbeta,
+                       float* scratch, int64_t N, int C, dgtd_dtype dt, dgtd_stream s);
+
 /* Bilinear resize of an NHWC map, x [B,Hi,Wi,C] -> y [B,Ho,Wo,C]: F.interpolate(mode="bilinear") with either align_corners
  * convention - the x2 / x4 / x0.5 align_corners=True resizes between the Hitnet decoder levels (cod.py:757-789).  The backward
  * gathers, for every input pixel, the output pixels that read it (dx overwritten, no atomics).                               */

@@ -267,6 +267,88 @@ def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
     torch.testing.assert_close(hw2, gw2, atol=wtol * gw2.abs().max().item() + 1e-6, rtol=wtol)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (8, 32, 64, 64), (3, 64, 12, 20), (1, 32, 7, 9)])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("layer", ["native", "ctypes"])
+def test_sam_matches_torch_composition(dgtd, B, C, H, W, dtype, layer):
+    """SAM (cod.py:454-506) in two launches each way against the plain torch composition in fp32: output, both input gradients and
+    the four weight gradients (the weights gate BOTH inputs, so each gradient sums two paths)."""
+    from dgtd.ops import hitnet as H_
+    R = max(C // 16, 1)
+    xh = _rand(B, C, H, W, seed=1, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    xl = _rand(B, C, H, W, seed=2, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    g = _rand(B, C, H, W, seed=3, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    ws = [(_rand(R, C, seed=4) / math.sqrt(C)).requires_grad_(), (_rand(C, R, seed=5) / math.sqrt(R)).requires_grad_(),
+          (_rand(R, C, seed=6) / math.sqrt(C)).requires_grad_(), (_rand(1, R, seed=7) / math.sqrt(R)).requires_grad_()]
+
+    def gate(x):
+        y = x.mean((2, 3))
+        a = torch.sigmoid(F.linear(F.relu(F.linear(y, ws[0])), ws[1]))
+        b = torch.sigmoid(F.linear(F.relu(F.linear(y, ws[2])), ws[3]))
+        return x * a[:, :, None, None] * b[:, :, None, None]
+
+    hr, lr = xh.float().requires_grad_(), xl.float().requires_grad_()
+    ref = gate(hr) + gate(lr)
+    gref = torch.autograd.grad(ref, (hr, lr, *ws), g.float())
+    hs, ls = xh.clone().requires_grad_(), xl.clone().requires_grad_()
+    out = dgtd.ops.sam(hs, ls, *ws) if layer == "native" else H_._SamFn.apply(hs, ls, *ws)
+    got = torch.autograd.grad(out, (hs, ls, *ws), g)
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    for a, b in zip(got[:2], gref[:2]):
+        torch.testing.assert_close(a.float(), b, atol=tol, rtol=tol)
+    wtol = 2e-4 if dtype == torch.float32 else 3e-2
+    for a, b in zip(got[2:], gref[2:]):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        torch.testing.assert_close(a, b, atol=wtol * b.abs().max().item() + 1e-6, rtol=wtol)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(8, 32, 16, 16), (8, 32, 64, 64), (2, 32, 128, 128), (3, 64, 12, 20), (1, 8, 5, 7), (2, 128, 9, 9)])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("layer", ["native", "ctypes"])
+def test_batch_norm_matches_torch(dgtd, B, C, H, W, dtype, layer):
+    """nn.BatchNorm2d of BasicConv2d (cod.py:359, :366), training mode: output, saved running statistics, num_batches_tracked and the
+    three gradients against torch's own BatchNorm2d on the fp32 copy of the same input; then the eval-mode map of the moved statistics."""
+    from dgtd.ops import hitnet as H_
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * _rand(C, seed=11)); bn.bias.copy_(0.2 * _rand(C, seed=12))
+        bn.running_mean.copy_(0.1 * _rand(C, seed=13)); bn.running_var.copy_(1 + 0.2 * _rand(C, seed=14).abs())
+    import copy
+    ref_bn = copy.deepcopy(bn)
+    x = (1.5 * _rand(B, C, H, W, seed=1) + 0.7).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = _rand(B, C, H, W, seed=2, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_()
+    ref = ref_bn(xr)
+    gref = torch.autograd.grad(ref, (xr, ref_bn.weight, ref_bn.bias), g.float())
+    xs = x.clone().requires_grad_()
+    assert dgtd.ops.batch_norm_supported(xs, bn)
+    if layer == "native":
+        out = dgtd.ops.batch_norm(xs, bn)
+    else:
+        out = H_._BatchNormFn.apply(xs, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, True, bn.momentum, bn.eps)
+    got = torch.autograd.grad(out, (xs, bn.weight, bn.bias), g)
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=tol)
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, atol=1e-5, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    torch.testing.assert_close(got[0].float(), gref[0], atol=tol, rtol=tol)
+    wtol = 2e-4 if dtype == torch.float32 else 2e-2
+    for a, b in zip(got[1:], gref[1:]):
+        assert a.dtype == torch.float32
+        torch.testing.assert_close(a, b, atol=wtol * b.abs().max().item() + 1e-5, rtol=wtol)
+    bn.eval(); ref_bn.eval()
+    with torch.no_grad():
+        assert dgtd.ops.batch_norm_supported(x, bn)
+        torch.testing.assert_close(dgtd.ops.batch_norm(x, bn).float(), ref_bn(x.float()), atol=tol, rtol=tol)
+    assert int(bn.num_batches_tracked) == 1
+    assert not dgtd.ops.batch_norm_supported(x.clone().requires_grad_(), bn)      # eval mode + gradient wanted: torch's path
+
+
 # ---------------------------------------------------------------------------------------------- dense 3x3 convolution (NHWC bf16 MFMA)
 def _conv_ref(x, w, b, relu):
     y = F.conv2d(x.float(), w.float(), b.float() if b is not None else None, padding=1)
