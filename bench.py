@@ -152,7 +152,7 @@ def main():
     net = dgtd.nn.cod(compute_dtype=dtype, backbone=args.backbone).to(dev)
     net = net.train() if train else net.eval()
     dgtd.dist.broadcast_parameters(net)
-    reducer = dgtd.dist.GradReducer(net, working_dtype=dtype)
+    reducer = dgtd.dist.GradReducer(net, working_dtype=dtype, bucket_bytes=int(os.environ.get("DGTD_BUCKET_MB", "64")) << 20)
     flat_opt = os.environ.get("DGTD_FLAT_ADAMW", "1") != "0"
     scaler = dgtd.runner.LossScaler(dev) if (train and dtype == torch.float16) else None   # AmpOptimWrapper's GradScaler (config/sod.yml:57)
     # AdamW over the reducer's flat buckets (one launch per lr run, 16-bit working copies rewritten in the same pass), or torch's

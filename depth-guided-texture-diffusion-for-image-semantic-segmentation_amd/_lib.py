@@ -70,6 +70,7 @@ SIGNATURES = {
     "dgtd_diffuse_tail_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "dgtd_adamw_flat": (_i, [_fp, _fp, _fp, _fp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "dgtd_adamw_flat_amp": (_i, [_fp, _fp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp]),
+    "dgtd_adamw_flat_g16": (_i, [_fp, _vp, _fp, _fp, _vp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp]),
     "dgtd_found_inf": (_i, [_fp, _i64, _fp, _vp]),
     "dgtd_loss_scale_update": (_i, [_fp, _f, _f, _i, _vp]),
     "dgtd_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

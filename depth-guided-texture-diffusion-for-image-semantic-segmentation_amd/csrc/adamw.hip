@@ -23,7 +23,9 @@ __device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, 
 template <typename WT>
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, WT* __restrict__ w, int64_t n, int64_t head,
-                                                         AdamArgs a, const float* __restrict__ amp, const float* __restrict__ lr_dev) {
+                                                         AdamArgs a, const float* __restrict__ amp, const float* __restrict__ lr_dev,
+                                                         const WT* __restrict__ g16) {
+  // g16 != NULL: the gradient is the 16-bit all-reduce payload itself (same phase as w), g is not read
   // amp = the loss scaler's device state { scale, growth_tracker, 1/scale, found_inf, steps taken } or NULL
   // lr_dev = the learning rate in device memory (a captured hipGraph replays with whatever the schedule wrote there) or NULL
   float gs = 1.f;
@@ -41,7 +43,14 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
   for (int64_t i = tid; i < body4; i += nth) {
     const int64_t o = head + i * 4;
     f32x4 pv = *reinterpret_cast<f32x4*>(p + o), mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+    f32x4 gv;
+    if (g16) {
+      const W4 hv = *reinterpret_cast<const W4*>(g16 + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gv[j] = (float)hv[j];
+    } else {
+      gv = *reinterpret_cast<const f32x4*>(g + o);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { float mj = mv[j], vj = vv[j]; pv[j] = adam_one(pv[j], gv[j] * gs, mj, vj, a); mv[j] = mj; vv[j] = vj; }
     *reinterpret_cast<f32x4*>(p + o) = pv;
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
   if (tid < nscal) {
     const int64_t o = tid < head ? tid : tail0 + (tid - head);
     float mj = m[o], vj = v[o];
-    const float pj = adam_one(p[o], g[o] * gs, mj, vj, a);
+    const float pj = adam_one(p[o], (g16 ? (float)g16[o] : g[o]) * gs, mj, vj, a);
     p[o] = pj; m[o] = mj; v[o] = vj;
     if (w) w[o] = (WT)pj;
   }
@@ -96,11 +105,13 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth
 
 }  // namespace
 
-extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
-                                   float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                                   const float* amp_state, const float* lr_dev, dgtd_stream s) {
-  DGTD_PROF(s, DGTD_HBM, (w ? 30.0 : 28.0) * n, "dgtd_adamw_flat[n=%lld]", (long long)n);
-  DGTD_REQUIRE(n > 0 && p && g && m && v, "adamw_flat: bad arguments");
+static int adamw_impl(float* p, const float* g, const void* g16, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                      const float* amp_state, const float* lr_dev, dgtd_stream s) {
+  DGTD_PROF(s, DGTD_HBM, (w ? 30.0 : 28.0) * n - (g16 ? 2.0 * n : 0.0), "dgtd_adamw_flat[n=%lld%s]", (long long)n, g16 ? ",g16" : "");
+  DGTD_REQUIRE(n > 0 && p && (g || g16) && m && v, "adamw_flat: bad arguments");
+  if (!g) g = p;                                                             // never read; keeps the phase checks below trivially true
+  DGTD_REQUIRE(!g16 || (DGTD_IS_HALF(w_dt) && ((uintptr_t)g16 % 8) * 2 == (uintptr_t)p % 16), "adamw_flat: the 16-bit gradient must share the phase of the masters");
   DGTD_REQUIRE(amp_state || (bias_correction1 > 0.f && bias_correction2 > 0.f), "adamw_flat: bias corrections must be positive");
   DGTD_REQUIRE(!w || DGTD_IS_HALF(w_dt), "adamw_flat: the working copy is bf16 or fp16, got dtype %d", (int)w_dt);
   const uintptr_t ap = (uintptr_t)p;
@@ -110,10 +121,24 @@ extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v,
   const int64_t head = std::min<int64_t>(n, ((16 - (int64_t)(ap % 16)) % 16) / 4);
   AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f / bias_correction1, 1.f / sqrtf(bias_correction2), (float)log((double)beta1), (float)log((double)beta2)};
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((n + 3) / 4 + 8, 256), 8192));
-  if (w_dt == DGTD_F16) hipLaunchKernelGGL(adamw_flat_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (f16_t*)w, n, head, a, amp_state, lr_dev);
-  else hipLaunchKernelGGL(adamw_flat_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)w, n, head, a, amp_state, lr_dev);
+  if (w_dt == DGTD_F16) hipLaunchKernelGGL(adamw_flat_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (f16_t*)w, n, head, a, amp_state, lr_dev, (const f16_t*)g16);
+  else hipLaunchKernelGGL(adamw_flat_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)w, n, head, a, amp_state, lr_dev, (const bf16_t*)g16);
   DGTD_CHECK_LAUNCH("adamw_flat");
   return 0;
+}
+
+extern "C" int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                                   const float* amp_state, const float* lr_dev, dgtd_stream s) {
+  DGTD_REQUIRE(g, "adamw_flat: bad arguments");
+  return adamw_impl(p, g, nullptr, m, v, w, w_dt, n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, amp_state, lr_dev, s);
+}
+
+extern "C" int dgtd_adamw_flat_g16(float* p, const void* g16, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                                   const float* amp_state, const float* lr_dev, dgtd_stream s) {
+  DGTD_REQUIRE(g16, "adamw_flat_g16: bad arguments");
+  return adamw_impl(p, nullptr, g16, m, v, w, w_dt, n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, amp_state, lr_dev, s);
 }
 
 extern "C" int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1, float beta2,

@@ -353,8 +353,16 @@ extern "C" int dgtd_gemm_supported(int M, int N, int K, dgtd_dtype dt) {
          (int64_t)M * K < (1ll << 31) && (int64_t)N * K < (1ll << 31) ? 1 : 0;
 }
 
+// roofline label of a call: 2 M N K flop over e (M K + N K + maps M N) bytes (maps = the [M,N] tensors the epilogue reads or writes); above the
+// ridge (2.5 PF / 8 TB/s = 312 flop/B) the call is priced against the MFMA peak, below it against HBM.  With K = 512 and two [M,N] maps
+// (the ConvNeXt / Mlp expansions) the intensity is 2 K / (2 e) = 256 flop/B: those calls are HBM-bound by their activation traffic.
+#define GEMM_PROF(s, maps, ...)                                                                                        \
+  const double prof_flops_ = 2.0 * M * N * K, prof_bytes_ = 2.0 * ((double)M * K + (double)N * K + (double)(maps) * M * N); \
+  const bool prof_mfma_ = prof_flops_ > 312.5 * prof_bytes_;                                                           \
+  DGTD_PROF(s, prof_mfma_ ? DGTD_MFMA : DGTD_HBM, prof_mfma_ ? prof_flops_ : prof_bytes_, __VA_ARGS__)
+
 extern "C" int dgtd_gemm_bias(const void* a, const void* b, const void* bias, void* d, int M, int N, int K, dgtd_dtype dt, dgtd_stream s) {
-  DGTD_PROF(s, DGTD_MFMA, 2.0 * M * N * K, "dgtd_gemm_bias[M=%d,N=%d,K=%d]", M, N, K);
+  GEMM_PROF(s, 1, "dgtd_gemm_bias[M=%d,N=%d,K=%d]", M, N, K);
   if (int rc = check_common(a, b, d, M, N, K, dt, "gemm_bias")) return rc;
   GemmArgs g{a, b, bias, d, nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 1};
   return dispatch<EPI_BIAS>(g, dt, (hipStream_t)s);
@@ -362,7 +370,7 @@ extern "C" int dgtd_gemm_bias(const void* a, const void* b, const void* bias, vo
 
 extern "C" int dgtd_gemm_bias_gelu(const void* a, const void* b, const void* bias, void* pre, void* h, int M, int N, int K, dgtd_dtype dt,
                                    dgtd_stream s) {
-  DGTD_PROF(s, DGTD_MFMA, 2.0 * M * N * K, "dgtd_gemm_bias_gelu[M=%d,N=%d,K=%d]", M, N, K);
+  GEMM_PROF(s, pre ? 2 : 1, "dgtd_gemm_bias_gelu[M=%d,N=%d,K=%d]", M, N, K);
   if (int rc = check_common(a, b, h, M, N, K, dt, "gemm_bias_gelu")) return rc;
   DGTD_REQUIRE(!pre || (uintptr_t)pre % 16 == 0, "gemm_bias_gelu: pre must be 16-byte aligned");
   GemmArgs g{a, b, bias, pre, h, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 1};
@@ -371,7 +379,7 @@ extern "C" int dgtd_gemm_bias_gelu(const void* a, const void* b, const void* bia
 
 extern "C" int dgtd_gemm_bias_residual(const void* a, const void* b, const void* bias, const void* x, const float* scale, const float* gamma,
                                        void* y, void* out, int M, int N, int K, int64_t rows_per_sample, dgtd_dtype dt, dgtd_stream s) {
-  DGTD_PROF(s, DGTD_MFMA, 2.0 * M * N * K, "dgtd_gemm_bias_residual[M=%d,N=%d,K=%d]", M, N, K);
+  GEMM_PROF(s, y ? 3 : 2, "dgtd_gemm_bias_residual[M=%d,N=%d,K=%d]", M, N, K);
   if (int rc = check_common(a, b, out, M, N, K, dt, "gemm_bias_residual")) return rc;
   DGTD_REQUIRE(x && (uintptr_t)x % 16 == 0 && (!y || (uintptr_t)y % 16 == 0), "gemm_bias_residual: x / y must be 16-byte aligned");
   DGTD_REQUIRE(!scale || (rows_per_sample > 0 && M % rows_per_sample == 0), "gemm_bias_residual: bad rows_per_sample");
@@ -383,7 +391,7 @@ extern "C" int64_t dgtd_gemm_gelu_bwd_workspace(int M, int N) { return (int64_t)
 
 extern "C" int dgtd_gemm_gelu_bwd(const void* dy, const void* w_t, const void* pre, void* dpre, void* colsum_ws, int* nblocks, int M, int N,
                                   int K, dgtd_dtype dt, dgtd_stream s) {
-  DGTD_PROF(s, DGTD_MFMA, 2.0 * M * N * K, "dgtd_gemm_gelu_bwd[M=%d,N=%d,K=%d]", M, N, K);
+  GEMM_PROF(s, 2, "dgtd_gemm_gelu_bwd[M=%d,N=%d,K=%d]", M, N, K);
   if (int rc = check_common(dy, w_t, dpre, M, N, K, dt, "gemm_gelu_bwd")) return rc;
   DGTD_REQUIRE(pre && (uintptr_t)pre % 16 == 0, "gemm_gelu_bwd: pre must be 16-byte aligned");
   GemmArgs g{dy, w_t, nullptr, dpre, nullptr, pre, nullptr, nullptr, (float*)colsum_ws, M, N, K, 0, 1};

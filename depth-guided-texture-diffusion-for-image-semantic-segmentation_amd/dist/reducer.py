@@ -380,9 +380,11 @@ class GradReducer:
             go()
 
     @torch.no_grad()
-    def wait_bucket(self, index: int) -> None:
+    def wait_bucket(self, index: int, widen: bool = True) -> None:
         """Make the CURRENT stream wait for bucket ``index``'s all-reduce and widen its 16-bit payload into the fp32 bucket (no-op when
-        nothing was launched for it).  With RCCL the wait is a stream-level event wait (capturable); with gloo the host blocks."""
+        nothing was launched for it).  With RCCL the wait is a stream-level event wait (capturable); with gloo the host blocks.
+        ``widen=False``: the consumer reads the 16-bit payload itself (FlatAdamW, dgtd_adamw_flat_g16); the fp32 bucket's working-copy
+        segment is then NOT refreshed for this step."""
         b = self.buckets[index]
         works = b.get("works")
         if not works:
@@ -393,7 +395,7 @@ class GradReducer:
         # event to the process group's cache, where the next collective of the same capture would re-record it)
         self._works.extend(works)
         b["works"] = []
-        if b["g16"] is not None:
+        if widen and b["g16"] is not None:
             b["flat"][:b["n_work"]].copy_(b["g16"])
 
     def finish(self) -> None:

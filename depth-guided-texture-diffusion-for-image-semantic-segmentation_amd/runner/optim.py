@@ -3,6 +3,7 @@ mmengine's ``paramwise_cfg.custom_keys`` semantics = the LONGEST matching substr
 ``bypass_duplicate`` = a parameter reachable under several names (the shared PReLU) is added once."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -69,6 +70,9 @@ class LossScaler:
         self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
         self.growth_interval = int(sd["growth_interval"])
         self.state.copy_(torch.tensor([sd["scale"], float(sd["_growth_tracker"]), 1.0 / sd["scale"], 0.0, float(sd.get("steps_taken", 0))]))
+
+
+_ADAM_G16 = os.environ.get("DGTD_ADAM_G16", "1") != "0"      # 0: always widen the 16-bit all-reduce payload into the fp32 bucket first
 
 
 class FlatAdamW:
@@ -159,8 +163,11 @@ class FlatAdamW:
                 L.call("dgtd_found_inf", b["flat"].data_ptr(), b["flat"].numel(), amp + 12, st)
         lrp = self._lr_dev.data_ptr() if self._lr_dev is not None else None
         for b, slots, runs, state in zip(self.reducer.buckets, self.slots, self.runs, self.state):
-            if self.pipelined:                      # the bucket's all-reduce runs on the reducer's side stream: join it bucket by bucket
-                self.reducer.wait_bucket(b["index"])
+            # pipelined: the bucket's all-reduce runs on the reducer's side stream and is joined bucket by bucket; without a loss scaler
+            # (no found_inf pass over the fp32 bucket) the working-copy segment is updated straight from the 16-bit payload
+            g16 = b.get("g16") if (self.pipelined and self.scaler is None and b.get("works") and _ADAM_G16) else None
+            if self.pipelined:
+                self.reducer.wait_bucket(b["index"], widen=g16 is None)
             p, g, m, v, w, nw = b["mflat"], b["flat"], state["exp_avg"], state["exp_avg_sq"], b["wflat"], b["n_work"]
             # world 1: parameters without a gradient this step are skipped, like torch.optim.AdamW does.  N > 1: ``missing`` is
             # rank-local while the all-reduced slot holds the average over every rank (zero from the ranks that did not use the
@@ -169,7 +176,9 @@ class FlatAdamW:
                 runs = self._merge(slots, nw, set(b["missing"]))
             for lo, hi, gi in runs:
                 wp = (w.data_ptr() + 2 * lo) if (w is not None and hi <= nw) else None
-                L.call("dgtd_adamw_flat_amp", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, wp,
+                direct = g16 is not None and hi <= nw
+                L.call("dgtd_adamw_flat_g16" if direct else "dgtd_adamw_flat_amp", p.data_ptr() + 4 * lo,
+                       (g16.data_ptr() + 2 * lo) if direct else (g.data_ptr() + 4 * lo), m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, wp,
                        self._w_dt, hi - lo, float(self.param_groups[gi]["lr"]), b1, b2, self.eps,
                        float(self.param_groups[gi]["weight_decay"]), bc1, bc2, amp,
                        (lrp + 4 * gi) if lrp is not None else None, st)

@@ -347,6 +347,11 @@ int dgtd_adamw_flat(float* p, const float* g, float* m, float* v, void* w_bf16, 
 int dgtd_adamw_flat_amp(float* p, const float* g, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
                         const float* amp_state, const float* lr_dev, dgtd_stream s);
+/* The same update with the gradient read from the 16-bit all-reduce payload g16 [n] (dtype w_dt, at the phase of w) instead of an fp32
+ * bucket: the N > 1 step does not widen the payload into fp32 first (dist.GradReducer buckets, config/sod.yml:11's DDP reduction).   */
+int dgtd_adamw_flat_g16(float* p, const void* g16, float* m, float* v, void* w, dgtd_dtype w_dt, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                        const float* amp_state, const float* lr_dev, dgtd_stream s);
 /* found[0] = 1 when g[0,n) (fp32, the still scaled gradients) holds an inf or a NaN; untouched otherwise.                        */
 int dgtd_found_inf(const float* g, int64_t n, float* found, dgtd_stream s);
 /* GradScaler.update() on the device: state fp32 [5] (layout above); found_inf != 0: scale *= backoff, tracker = 0; else steps += 1,

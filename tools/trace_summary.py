@@ -18,7 +18,7 @@ def category(n: str) -> str:
     if any(k in n for k in ("gemm_tn_kernel", "transpose_batched_kernel", "dkdv_reduce_kernel")):
         return "dgtd own GEMM (csrc/gemm.hip) + weight transposes"
     if any(k in n for k in ("dwconv", "ln_fwd", "ln_bwd", "sra_", "attn_delta", "diffus", "colsum", "scale_residual", "conv3x3", "bilinear_fwd_kernel", "bilinear_bwd_kernel",
-                            "prelu_", "ca_gate", "ca_apply", "pooled_sum", "loss_", "im2col", "col2im", "multi_copy", "multi_reduce", "ssim_", "found_inf", "preprocess", "resize_")):
+                            "prelu_", "ca_gate", "ca_apply", "pooled_sum", "loss_", "im2col", "col2im", "multi_copy", "multi_reduce", "ssim_", "found_inf", "preprocess", "resize_", "bn_partial", "bn_apply", "bn_bwd", "sam_")):
         return "dgtd HIP kernels"
     if "reduce_kernel" in n:
         return "torch reductions"
