@@ -94,6 +94,7 @@ SIGNATURES = {
     "dgtd_conv3x3_wgrad_batched": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dgtd_ca_gate_bwd": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "dgtd_ca_gate_bwd_rows": (_i, [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "dgtd_sam_supported": (_i, [_i, _i, _i, _i, _i]),
     "dgtd_sam_stats_floats": (_i64, [_i, _i, _i]),
     "dgtd_sam_scratch_floats": (_i64, [_i, _i]),

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_fused_kernel(const T* __rest
                                                                  const float* __restrict__ gate, const float* __restrict__ hidden,
                                                                  const float* __restrict__ pooled, const float* __restrict__ w1,
                                                                  const float* __restrict__ w2, T* __restrict__ dres, float* __restrict__ dw1,
-                                                                 float* __restrict__ dw2, int HW, int C, int R) {
+                                                                 float* __restrict__ dw2, int HW, int C, int R, int per_sample) {
   typedef typename Vec16<T>::type VT;
   constexpr int V = Vec16<T>::N;
   extern __shared__ float sh[];                 // own sample: dz[128] dh[32] gt[128] dm[128]; workgroup (0,0): + all samples dzA[B*128] dhA[B*32]
@@ -289,7 +289,17 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_fused_kernel(const T* __rest
     for (int j = 0; j < R; ++j) a += w1[j * C + tid] * dh[j];
     dm[tid] = a / (float)HW;                                  // d loss / d res[b][hw][c] through the mean
   }
-  if (blockIdx.x == 0 && b == 0) {                            // weight gradients: all samples, summed over the batch in sample order
+  if (per_sample) {
+    // rows mode: the first workgroup of every sample writes ITS sample's outer products { dh x mean | dz x hidden } as row b of dw1
+    // (row stride 2 R C); whoever owns the rows sums them later (the deferred flush's multi_reduce) - no serial walk over the batch
+    if (blockIdx.x == 0) {
+      float* row = dw1 + (size_t)b * 2 * R * C;
+      for (int i = tid; i < 2 * R * C; i += 256) {
+        if (i < R * C) { const int j = i / C, c = i % C; row[i] = dh[j] * (pooled[b * C + c] / (float)HW); }
+        else { const int k = i - R * C, c = k / R, j = k % R; row[i] = dz[c] * hidden[b * R + j]; }
+      }
+    }
+  } else if (blockIdx.x == 0 && b == 0) {                     // weight gradients: all samples, summed over the batch in sample order
     for (int i = tid; i < B * C; i += 256) {
       const int bb = i / C, c = i % C;
       const float gv = gate[bb * C + c];
@@ -504,8 +514,8 @@ extern "C" int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1,
 }
 
 // scratch fp32 [B*C (dmean) | 64*B*C (per-slice partial sums) | B*2*R*C (per-sample dw)]; dw1 [R,C], dw2 [C,R] overwritten; nothing to zero
-extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
-                                float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
+static int ca_gate_bwd_impl(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                            float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s, int per_sample) {
   DGTD_PROF(s, DGTD_HBM, 3.0 * dgtd_esize(dt) * B * HW * C, "dgtd_ca_gate_bwd[B=%d,HW=%d,C=%d]", B, HW, C);
   const int V = DGTD_IS_HALF(dt) ? 8 : 4;
   DGTD_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 128 && R > 0 && R <= 32 && C % V == 0, "ca_gate_bwd: unsupported sizes C=%d R=%d", C, R);
@@ -519,12 +529,12 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   else hipLaunchKernelGGL((pooled_sum_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)g, (const float*)res, partial, HW, C);
   DGTD_CHECK_LAUNCH("ca_dgate_sum");
   static const bool fused = !(getenv("DGTD_CA_FUSED") && getenv("DGTD_CA_FUSED")[0] == '0');
-  if (fused && B <= CA_MAXB) {
+  if (per_sample || (fused && B <= CA_MAXB)) {
     const int ax = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)HW * (C / V), 256 * 2), 128));
-    const size_t lds = (size_t)(416 + B * 160) * sizeof(float);
-    if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<f16_t>, dim3(ax, B), dim3(256), lds, st, (const f16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (f16_t*)dres, dw1, dw2, HW, C, R);
-    else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<bf16_t>, dim3(ax, B), dim3(256), lds, st, (const bf16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (bf16_t*)dres, dw1, dw2, HW, C, R);
-    else hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<float>, dim3(ax, B), dim3(256), lds, st, (const float*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (float*)dres, dw1, dw2, HW, C, R);
+    const size_t lds = (size_t)(416 + (per_sample ? 0 : B * 160)) * sizeof(float);
+    if (dt == DGTD_F16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<f16_t>, dim3(ax, B), dim3(256), lds, st, (const f16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (f16_t*)dres, dw1, dw2, HW, C, R, per_sample);
+    else if (dt == DGTD_BF16) hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<bf16_t>, dim3(ax, B), dim3(256), lds, st, (const bf16_t*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (bf16_t*)dres, dw1, dw2, HW, C, R, per_sample);
+    else hipLaunchKernelGGL(ca_apply_bwd_fused_kernel<float>, dim3(ax, B), dim3(256), lds, st, (const float*)g, (const float*)partial, gx, gate, hidden, pooled, w1, w2, (float*)dres, dw1, dw2, HW, C, R, per_sample);
     DGTD_CHECK_LAUNCH("ca_apply_bwd_fused");
     return 0;
   }
@@ -536,6 +546,19 @@ extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1,
   else hipLaunchKernelGGL(ca_apply_bwd_kernel<float>, dim3(ew_grid(rows * (C / V))), dim3(256), 0, st, (const float*)g, gate, (const float*)dmean, (float*)dres, rows, HW, C, (const float*)dwp, dw1, dw2, B, R);
   DGTD_CHECK_LAUNCH("ca_apply_bwd");
   return 0;
+}
+
+extern "C" int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                                float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  return ca_gate_bwd_impl(g, res, w1, w2, stats, dres, dw1, dw2, scratch, B, HW, C, R, dt, s, 0);
+}
+
+// the same with the weight gradients left as ONE ROW PER SAMPLE: dw_rows fp32 [B][2 R C] = { dh_b x mean_b | dz_b x hidden_b }; the caller
+// sums the rows (csrc_torch: the deferred flush adds them up together with the rows of the module's other calls)
+extern "C" int dgtd_ca_gate_bwd_rows(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                                     float* dw_rows, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s) {
+  DGTD_REQUIRE(B <= 65535, "ca_gate_bwd_rows: B=%d", B);
+  return ca_gate_bwd_impl(g, res, w1, w2, stats, dres, dw_rows, nullptr, scratch, B, HW, C, R, dt, s, 1);
 }
 
 extern "C" int dgtd_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, dgtd_dtype dt,

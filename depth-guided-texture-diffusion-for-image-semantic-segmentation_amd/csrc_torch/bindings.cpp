@@ -279,7 +279,7 @@ static std::map<const void*, Tensor> g_prelu_acc;
 static std::map<const void*, Tensor> g_conv_flip;        // weight -> its flipped copy, valid for one step (cleared at every flush)
 // the two 1x1 weights of a CAB's channel-attention MLP (cod.py:420-425) get one gradient per call of the module (4 per step): every call
 // writes its { dw1 | dw2 } row into a per-module buffer, the first call hands autograd the (unwritten) sums, the flush adds the rows up
-struct CaAcc { Tensor buf; int count, rc; void* out1; void* out2; };
+struct CaAcc { Tensor buf; int count, rc; void* out1; void* out2; int rows = 1; };   // rows: buffer rows written per call
 static std::map<const void*, CaAcc> g_ca_acc;            // key: the first weight's data pointer
 constexpr int CA_MAX_CALLS = 8;
 
@@ -467,7 +467,7 @@ static void flush_deferred_impl() {
   for (auto& kv : cas) {
     CaAcc& a = kv.second;
     keep_for_side(a.buf);
-    todo.push_back(PendingReduce{dgtd_reduce_entry{a.buf.data_ptr<float>(), a.count, 2 * a.rc, (float*)a.out1, a.rc, a.out2, (int32_t)DGTD_F32, 0, 0, nullptr}, a.buf});
+    todo.push_back(PendingReduce{dgtd_reduce_entry{a.buf.data_ptr<float>(), a.count * a.rows, 2 * a.rc, (float*)a.out1, a.rc, a.out2, (int32_t)DGTD_F32, 0, 0, nullptr}, a.buf});
   }
   g_flushed += (int64_t)(gemms.size() + todo.size() + dws.size());
   for (auto& p : todo) keep_for_side(p.ws);
@@ -1732,14 +1732,19 @@ struct CabFn : public torch::autograd::Function<CabFn> {
       if (it == g_ca_acc.end()) {
         dcw1 = at::empty({R, C, 1, 1}, x.options().dtype(at::kFloat));
         dcw2 = at::empty({C, R, 1, 1}, x.options().dtype(at::kFloat));
-        CaAcc acc{at::empty({CA_MAX_CALLS, 2 * R * C}, x.options().dtype(at::kFloat)), 0, (int)(R * C), dcw1.data_ptr(), dcw2.data_ptr()};
+        // one row PER SAMPLE and call: the gate backward leaves the batch sum to the flush (dgtd_ca_gate_bwd_rows), B rows per call
+        CaAcc acc{at::empty({(int64_t)CA_MAX_CALLS * B, 2 * R * C}, x.options().dtype(at::kFloat)), 0, (int)(R * C), dcw1.data_ptr(), dcw2.data_ptr(), B};
         it = g_ca_acc.emplace(ckey, acc).first;
       }
-      if (it->second.count < CA_MAX_CALLS) row = it->second.buf.data_ptr<float>() + (int64_t)(it->second.count++) * 2 * R * C;
+      if (it->second.count < CA_MAX_CALLS && it->second.rows == B) row = it->second.buf.data_ptr<float>() + (int64_t)(it->second.count++) * B * 2 * R * C;
       else ca_shared = false;                        // more calls than rows: this one goes through autograd's own accumulation
     }
-    check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), row,
-                           row + R * C, sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd");
+    if (ca_shared)
+      check(dgtd_ca_gate_bwd_rows(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), row,
+                                  sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd_rows");
+    else
+      check(dgtd_ca_gate_bwd(g.data_ptr(), res.data_ptr(), w1f.data_ptr<float>(), w2f.data_ptr<float>(), stats.data_ptr<float>(), dres.data_ptr(), row,
+                             row + R * C, sp + 2 * R * C, B, (int)HW, C, (int)R, code(x), stream()), "dgtd_ca_gate_bwd");
     if (!ca_shared) {
       dcw1 = small.narrow(0, 0, R * C).view({R, C, 1, 1});
       dcw2 = small.narrow(0, R * C, R * C).view({C, R, 1, 1});

@@ -257,6 +257,10 @@ int dgtd_ca_gate_fwd(const void* res, const void* x, const float* w1, const floa
 /* dres [B,HW,C], dw1 [R,C], dw2 [C,R] overwritten (d out / d x is the identity); scratch fp32 [B*C + 64*B*C + B*2*R*C]; nothing to zero. */
 int dgtd_ca_gate_bwd(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
                      float* dw1, float* dw2, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
+/* The same with the weight gradients left as one row per sample: dw_rows fp32 [B][2*R*C] = { dh_b x mean_b | dz_b x hidden_b } overwritten;
+ * the caller sums the rows (no serial walk over the batch inside the launch).                                                      */
+int dgtd_ca_gate_bwd_rows(const void* g, const void* res, const float* w1, const float* w2, const float* stats, void* dres,
+                          float* dw_rows, float* scratch, int B, int HW, int C, int R, dgtd_dtype dt, dgtd_stream s);
 
 /* SAM (twig/model/cod.py:454-506) over NHWC maps x_h, x_l [B,HW,C]: out = x_h G(x_h) + x_l G(x_l) with
  * G(x)[b][c] = sigmoid(W2 relu(W1 y))[c] * sigmoid(V2 relu(V1 y)), y = mean_hw(x)[b]; W1 [R,C], W2 [C,R] = SAM.fc (cod.py:459-464),

@@ -267,6 +267,33 @@ def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
     torch.testing.assert_close(hw2, gw2, atol=wtol * gw2.abs().max().item() + 1e-6, rtol=wtol)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(8, 96, 64, 64), (3, 64, 12, 20), (40, 32, 16, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=str)
+def test_ca_gate_bwd_rows_sum_to_the_batched_gradients(dgtd, B, C, H, W, dtype):
+    """dgtd_ca_gate_bwd_rows leaves one { dw1 | dw2 } row per sample (the deferred flush sums them with the rows of the module's other
+    calls): same dres bit for bit, and the rows add up to what dgtd_ca_gate_bwd sums inside its launch (also beyond its 32-sample cap)."""
+    L = dgtd._lib
+    R = C // 4
+    res = _rand(B, C, H, W, seed=1, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    x = _rand(B, C, H, W, seed=2, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    g = _rand(B, C, H, W, seed=3, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    w1 = (_rand(R, C, seed=4) / math.sqrt(C)).contiguous()
+    w2 = (_rand(C, R, seed=5) / math.sqrt(R)).contiguous()
+    stats = torch.empty(2 * B * C + B * R + 64 * B * C, dtype=torch.float32, device="cuda")
+    out = torch.empty_like(res)
+    L.call("dgtd_ca_gate_fwd", L.ptr(res), L.ptr(x), L.ptr(w1), L.ptr(w2), L.ptr(out), L.ptr(stats), B, H * W, C, R, L.dtype_code(res), L.stream_ptr())
+    small = torch.empty(2 * R * C + B * C + 64 * B * C + B * 2 * R * C, dtype=torch.float32, device="cuda")
+    d_a, d_b = torch.empty_like(res), torch.empty_like(res)
+    L.call("dgtd_ca_gate_bwd", L.ptr(g), L.ptr(res), L.ptr(w1), L.ptr(w2), L.ptr(stats), L.ptr(d_a), small[:R * C].data_ptr(), small[R * C:].data_ptr(),
+           small[2 * R * C:].data_ptr(), B, H * W, C, R, L.dtype_code(res), L.stream_ptr())
+    ref = small[:2 * R * C].clone()
+    rows = torch.full((B, 2 * R * C), float("nan"), dtype=torch.float32, device="cuda")
+    L.call("dgtd_ca_gate_bwd_rows", L.ptr(g), L.ptr(res), L.ptr(w1), L.ptr(w2), L.ptr(stats), L.ptr(d_b), L.ptr(rows), small[2 * R * C:].data_ptr(),
+           B, H * W, C, R, L.dtype_code(res), L.stream_ptr())
+    assert torch.equal(d_a, d_b)
+    torch.testing.assert_close(rows.sum(0), ref, atol=2e-5 * ref.abs().max().item() + 1e-7, rtol=1e-4)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (8, 32, 64, 64), (3, 64, 12, 20), (1, 32, 7, 9)])
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("layer", ["native", "ctypes"])
