@@ -42,6 +42,12 @@ def main():
     print("#  gap_us  queue  after -> before")
     for g in sorted(gaps, key=lambda g: -g[0])[:top]:
         print(f"{g[0] / 1e3:9.1f}  {g[3]:>5}  {str(g[1])[:70]}  ->  {g[2][:70]}")
+    if "--around" in sys.argv:       # the kernels on either side of the replay boundary (the step's first launches and the previous step's last)
+        n = int(sys.argv[sys.argv.index("--around") + 1])
+        print(f"# the {n} launches before and after the start of the step (us relative to the step's first launch; start, duration, queue, name)")
+        for r in rows[max(0, a - n):a + n]:
+            s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            print(f"{(s_ - t0) / 1e3:10.1f} {(e_ - s_) / 1e3:8.1f}  {r.get('Queue_Id', '?'):>4}  {r['Kernel_Name'][:90]}")
 
 
 if __name__ == "__main__":
