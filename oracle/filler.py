@@ -8,6 +8,8 @@ reference, and on the GPU box on the oracle restatement and on the HIP-backed mo
 """
 from __future__ import annotations
 
+import json
+import os
 import zlib
 
 import numpy as np
@@ -44,16 +46,76 @@ def uniform(key: str, n: int) -> np.ndarray:
     return _uniform(key, n, 3)
 
 
-_CACHE = {}   # (key, shape) -> fp32 tensor: a test session fills ~25 models with the same 114 M values (13 s each to generate)
+_CACHE = {}   # (key, shape) -> fp32 tensor: a test session fills ~25 models with the same 114 M values (13 - 22 s each to generate)
+
+# The same values for the processes a test SPAWNS (the 2-rank tests, the forced-all-reduce workers): one flat fp32 file + an index in
+# shared memory, written by the parent (save_disk_cache) and memory-mapped by the children.  The file name carries a checksum of this
+# source file, so a change of the rules below can never meet stale values.
+_DISK = None          # (flat fp32 memmap, {"key|shape": [offset, n]}) or False when there is no file
+_NEW = {}             # entries generated in this process that the file does not hold
+
+
+def _disk_paths():
+    import tempfile
+    with open(__file__, "rb") as f:
+        tag = zlib.crc32(f.read())
+    base = os.environ.get("DGTD_FILLER_CACHE_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    stem = os.path.join(base, f"dgtd_filler_{os.getuid()}_{tag:08x}")
+    return stem + ".npy", stem + ".json"
+
+
+def _disk():
+    global _DISK
+    if _DISK is None:
+        npy, idx = _disk_paths()
+        try:
+            with open(idx) as f:
+                index = json.load(f)
+            _DISK = (np.load(npy, mmap_mode="r"), index)
+        except (OSError, ValueError):
+            _DISK = False
+    return _DISK
+
+
+def save_disk_cache() -> bool:
+    """Write every fp32 value this process holds (generated or read) to the shared file; False when nothing new would be added."""
+    global _DISK
+    if not _NEW:
+        return False
+    npy, idx = _disk_paths()
+    index, parts, off = {}, [], 0
+    for (key, shape), t in _CACHE.items():
+        a = t.detach().reshape(-1).numpy()
+        index[key + "|" + ",".join(map(str, shape))] = [off, int(a.size)]
+        parts.append(a)
+        off += int(a.size)
+    flat = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+    tmp = f"{npy}.{os.getpid()}.tmp.npy"
+    np.save(tmp, flat)
+    os.replace(tmp, npy)
+    with open(f"{idx}.{os.getpid()}.tmp", "w") as f:
+        json.dump(index, f)
+    os.replace(f"{idx}.{os.getpid()}.tmp", idx)
+    _NEW.clear()
+    _DISK = None
+    return True
 
 
 def value_for(key: str, shape, dtype=torch.float32) -> torch.Tensor:
     """The filler's rule table, keyed on the reference's state_dict naming
     (twig/model/cod.py; key inventory in SURVEY.md §2.2)."""
     if dtype == torch.float32:
-        hit = _CACHE.get((key, tuple(shape)))
+        shape = tuple(shape)
+        hit = _CACHE.get((key, shape))
         if hit is None:
-            hit = _CACHE[(key, tuple(shape))] = _value_for(key, shape, dtype)
+            d = _disk()
+            ent = d[1].get(key + "|" + ",".join(map(str, shape))) if d else None
+            if ent is not None:
+                hit = torch.from_numpy(np.array(d[0][ent[0]:ent[0] + ent[1]], dtype=np.float32)).reshape(shape)
+            else:
+                hit = _value_for(key, shape, dtype)
+                _NEW[(key, shape)] = True
+            _CACHE[(key, shape)] = hit
         return hit
     return _value_for(key, shape, dtype)
 

@@ -41,3 +41,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # the filler's shared value file (oracle/filler.py: 458 MB in /dev/shm for the processes the 2-rank tests spawn) lives for one session
+    try:
+        from oracle import filler
+        for f in filler._disk_paths():
+            if os.path.exists(f):
+                os.remove(f)
+    except Exception:
+        pass

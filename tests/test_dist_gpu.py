@@ -77,31 +77,55 @@ def test_reducer_streams_and_hooks_two_ranks_one_gpu():
 
 
 # ------------------------------------------------------------------------------------------------ the real model, two ranks
-def _cod_worker(rank, world, port, q):
+def _flat_grads(net):
+    """All parameter gradients of ``net`` as ONE fp32 vector on the GPU, in named_parameters order, + [(name, numel)]."""
+    items = [(n, p.grad) for n, p in net.named_parameters() if p.grad is not None]
+    return torch.cat([g.detach().float().reshape(-1) for _, g in items]), [(n, g.numel()) for n, g in items]
+
+
+def _fingerprint(flat):
+    """Order-sensitive exact integer fingerprint of an fp32 vector (bit pattern, not value): equal on two ranks <=> same tensor, up to
+    2^-64 collisions.  Also the count of non-finite elements."""
+    bits = flat.contiguous().view(torch.int32).to(torch.int64)
+    w = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+    return [int(bits.sum().item()), int((bits * w).sum().item()), int((~torch.isfinite(flat)).sum().item())]
+
+
+def _cod_worker(rank, world, port, q, tmpdir):
     """One rank of a 2-rank job on the shared GPU: the real dgtd.nn.cod at 64x64, bf16 working copies, reducer + FlatAdamW, run twice
     in the same process group (starting a fresh model each time):
       'eager' = hooks gather + all-reduce buckets during backward (overlap on the side stream);
-      'split' = GraphedTrainStep, graph A | bucketed all-reduce | graph B (gloo cannot be captured)."""
+      'split' = GraphedTrainStep, graph A | bucketed all-reduce | graph B (gloo cannot be captured).
+    The ranks compare their gradients / weights with each other through exact fingerprints (all_gather_object); rank 0 leaves its
+    gradient vector in ``tmpdir`` for the comparison with the single-process reference (458 MB per mode: a file, not a pickle)."""
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
         os.environ["DGTD_GEMM_TUNE"] = "0"     # the library GEMM plan = the heuristic's first answer in every process (see _reference_worker)
+        import copy
+        import time
+        torch.set_num_threads(4)               # three processes build a 114 M-parameter model at once: 3 x 16 spinning OpenMP threads on
+        t0, marks = time.perf_counter(), []    # 16 cores made that take 116 s instead of 8
+        mark = lambda what: marks.append((what, round(time.perf_counter() - t0, 1)))
         import dgtd
         from oracle import filler
+        mark("imports")
         torch.cuda.set_device(0)
         dgtd.dist.init_process_group("gloo")
         S, B = 64, 2
         x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))     # every rank its own samples
         batch = {"raw": None, "input": x, "label": l, "depth": d}
+        base = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+        filler.fill_module(base)                # values from the parent's shared file (oracle/filler.py), seconds instead of 20
+        mark("model built + filled")
         out = {}
         for mode in ("eager", "split"):
-            net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
-            filler.fill_module(net)
-            net = net.cuda().train()
+            net = copy.deepcopy(base).cuda().train()
             dgtd.dist.broadcast_parameters(net)
             red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
             assert red.world == 2 and red.comm16 and len(red.buckets) >= 4 and red.comm_stream is not None
             opt = dgtd.runner.FlatAdamW(red, lr=1e-4, graph_safe=True)
-            losses, grads = [], None
+            mark(f"{mode}: replica + broadcast + reducer + optimizer")
+            losses, grads, names = [], None, None
             if mode == "eager":
                 for _ in range(2):
                     red.zero_grad()
@@ -110,7 +134,7 @@ def _cod_worker(rank, world, port, q):
                     red.finish()
                     if grads is None:
                         torch.cuda.synchronize()
-                        grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in net.named_parameters() if p.grad is not None}
+                        grads, names = _flat_grads(net)
                     opt.step()
                     losses.append(loss.item())
             else:
@@ -121,14 +145,22 @@ def _cod_worker(rank, world, port, q):
                     losses.append(stepper(batch).item())
                     if grads is None:
                         torch.cuda.synchronize()
-                        grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in net.named_parameters() if p.grad is not None}
+                        grads, names = _flat_grads(net)
                 stepper.release()
             torch.cuda.synchronize()
-            weights = {n: p.detach().float().cpu().numpy().copy() for n, p in net.named_parameters()}
+            mark(f"{mode}: steps")
+            weights = torch.cat([p.detach().float().reshape(-1) for p in net.parameters()])
+            mine = {"grads": _fingerprint(grads), "weights": _fingerprint(weights), "n_grads": len(names)}
+            both = [None, None]
+            torch.distributed.all_gather_object(both, mine)
             bn = net.hitnet.Translayer2_1.bn.running_mean.detach().cpu().numpy().copy()
-            out[mode] = (grads, weights, losses, bn)
-            del net, red, opt
+            if rank == 0:
+                np.save(os.path.join(tmpdir, f"grads_{mode}.npy"), grads.cpu().numpy())
+            out[mode] = {"both": both, "losses": losses, "bn": bn, "names": names if rank == 0 else None}
+            del net, red, opt, grads, weights
             torch.distributed.barrier()
+            mark(f"{mode}: fingerprints + file")
+        out["timing"] = marks
         q.put((rank, out, None))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -138,7 +170,7 @@ def _cod_worker(rank, world, port, q):
         raise
 
 
-def _reference_worker(q):
+def _reference_worker(q, tmpdir):
     """world 1, same weights, own process: the gradient of the MEAN of the two ranks' losses = the mean of the per-rank gradients, each
     rank's batch through its own forward (BatchNorm statistics are per rank in the reference: plain BatchNorm2d, cod.py:362).
     Own process + DGTD_GEMM_TUNE=0 like the ranks: the library GEMM plans are otherwise picked by TIMING candidates once per process,
@@ -146,14 +178,16 @@ def _reference_worker(q):
     (measured 4-6 % pooled) - the bf16 noise floor of this model, not a property of the reducer."""
     try:
         os.environ["DGTD_GEMM_TUNE"] = "0"
+        import copy
+        torch.set_num_threads(4)
         import dgtd
         from oracle import filler
         S, B = 64, 2
-        acc, losses = None, []
+        base = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
+        filler.fill_module(base)
+        acc, names, losses = None, None, []
         for rank in range(2):
-            net = dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16)
-            filler.fill_module(net)
-            net = net.cuda().train()
+            net = copy.deepcopy(base).cuda().train()
             red = dgtd.dist.GradReducer(net, bucket_bytes=16 << 20, working_dtype=torch.bfloat16)
             x, d, l = (t.cuda() for t in filler.synthetic_batch(B, S, seed=100 + rank))
             red.zero_grad()
@@ -161,11 +195,12 @@ def _reference_worker(q):
             loss.backward()
             red.finish()
             torch.cuda.synchronize()
-            g = {n: p.grad.detach().float().cpu().numpy() / 2 for n, p in net.named_parameters() if p.grad is not None}
-            acc = g if acc is None else {n: acc[n] + g[n] for n in acc}
+            g, names = _flat_grads(net)
+            acc = g / 2 if acc is None else acc + g / 2
             losses.append(loss.item())
             del net, red
-        q.put(("ref", (acc, losses), None))
+        np.save(os.path.join(tmpdir, "grads_ref.npy"), acc.cpu().numpy())
+        q.put(("ref", {"losses": losses, "names": names}, None))
     except Exception:
         import traceback
         q.put(("ref", "ERROR: " + traceback.format_exc(), None))
@@ -177,41 +212,57 @@ def test_real_model_two_ranks_one_gpu():
     from inside the hooks, 16-bit all-reduce payload) under a 2-rank reducer: both ranks hold the same averaged gradient, it equals the
     single-process mean of the per-rank gradients within the bf16 budget, replicas stay in lock-step after AdamW, BN statistics stay
     per rank - once with hook-driven overlap ("eager"), once through the captured split step ("split"); one process group, one reference."""
+    import shutil
+    import tempfile
+    import dgtd
+    from oracle import filler
+    filler.fill_module(dgtd.nn.cod(drop_path_rate=0.0, compute_dtype=torch.bfloat16))    # generate once here (the later model tests of
+    filler.save_disk_cache()                                                             # this session reuse it), share it with the children
     world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_cod_worker, args=(r, world, port, q)) for r in range(world)]
-    procs.append(ctx.Process(target=_reference_worker, args=(q,)))
-    for p in procs:
-        p.start()
-    res = {}
-    for _ in range(world + 1):
-        r, payload, _ = q.get(timeout=900)
-        assert not isinstance(payload, str), f"rank {r}: {payload}"
-        res[r] = payload
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    want, lref = res["ref"]
-    den = sum(float((want[n].astype(np.float64) ** 2).sum()) for n in want)
-    for mode in ("eager", "split"):
-        (g0, w0, l0, bn0), (g1, w1, l1, bn1) = res[0][mode], res[1][mode]
-        assert set(g0) == set(g1) and len(g0) > 800
-        for n in g0:
-            assert np.array_equal(g0[n], g1[n]), (mode, n)               # the all-reduced gradient is the same tensor on both ranks
-            assert np.isfinite(g0[n]).all(), (mode, n)
-        for n in w0:
-            assert np.array_equal(w0[n], w1[n]), (mode, n)               # replicas in lock-step after two optimizer steps
-        assert not np.array_equal(bn0, bn1)                              # BatchNorm statistics are per rank (no SyncBN in the reference)
-        assert abs(l0[0] - lref[0]) < 2e-2 * abs(lref[0]) and abs(l1[0] - lref[1]) < 2e-2 * abs(lref[1]), (mode, l0, l1, lref)
-        # element-level agreement with the single-process mean gradient: the bf16 payload rounding
-        errs = {n: float(((g0[n].astype(np.float64) - want[n]) ** 2).sum()) for n in want}
-        num = sum(errs.values())
-        rel = (num / den) ** 0.5
-        top = sorted(((e / max(num, 1e-300), n) for n, e in errs.items()), reverse=True)[:4]
-        print(f"[{mode}] 2-rank vs single-process mean gradient: pooled rel L2 {rel:.4f} (budget 0.005); largest shares of the error: "
-              f"{[(n, round(sh, 3)) for sh, n in top]}")
-        assert rel < 0.005, (mode, rel, top)      # measured 0.002 - 0.003
+    tmpdir = tempfile.mkdtemp(prefix="dgtd_2rank_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cod_worker, args=(r, world, port, q, tmpdir)) for r in range(world)]
+        procs.append(ctx.Process(target=_reference_worker, args=(q, tmpdir)))
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(world + 1):
+            r, payload, _ = q.get(timeout=900)
+            assert not isinstance(payload, str), f"rank {r}: {payload}"
+            res[r] = payload
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        print("rank 0 timeline (s):", res[0]["timing"])
+        want = np.load(os.path.join(tmpdir, "grads_ref.npy"), mmap_mode="r")
+        lref, names = res["ref"]["losses"], res["ref"]["names"]
+        den = float(np.dot(want.astype(np.float64), want.astype(np.float64)))
+        for mode in ("eager", "split"):
+            r0, r1 = res[0][mode], res[1][mode]
+            assert r0["names"] == names and len(names) > 800
+            f0, f1 = r0["both"]
+            assert f0 == r1["both"][0] and f1 == r1["both"][1]                   # both ranks saw the same pair of reports
+            assert f0["grads"] == f1["grads"] and f0["grads"][2] == 0, (mode, f0, f1)      # the all-reduced gradient is the same (finite) tensor on both ranks
+            assert f0["weights"] == f1["weights"] and f0["weights"][2] == 0, (mode, f0, f1)   # replicas in lock-step after two optimizer steps
+            assert f0["n_grads"] == f1["n_grads"] == len(names)
+            assert not np.array_equal(r0["bn"], r1["bn"])                        # BatchNorm statistics are per rank (no SyncBN in the reference)
+            l0, l1 = r0["losses"], r1["losses"]
+            assert abs(l0[0] - lref[0]) < 2e-2 * abs(lref[0]) and abs(l1[0] - lref[1]) < 2e-2 * abs(lref[1]), (mode, l0, l1, lref)
+            # element-level agreement with the single-process mean gradient: the bf16 payload rounding
+            got = np.load(os.path.join(tmpdir, f"grads_{mode}.npy"), mmap_mode="r")
+            assert got.shape == want.shape
+            e2 = (got.astype(np.float64) - want.astype(np.float64)) ** 2
+            num = float(e2.sum())
+            rel = (num / den) ** 0.5
+            ends = np.cumsum([n for _, n in names])
+            shares = np.add.reduceat(e2, np.concatenate(([0], ends[:-1]))) / max(num, 1e-300)
+            top = [(names[k][0], round(float(shares[k]), 3)) for k in np.argsort(-shares)[:4]]
+            print(f"[{mode}] 2-rank vs single-process mean gradient: pooled rel L2 {rel:.4f} (budget 0.005); largest shares of the error: {top}")
+            assert rel < 0.005, (mode, rel, top)      # measured 0.002 - 0.003
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
 
 
 def test_bench_control_flow_two_ranks_one_gpu(tmp_path):
