@@ -288,10 +288,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmArgs g) {
   }
 }
 
-// out[c][r] = in[r][c] for a batch of [rows][cols] 16-bit matrices (the once-per-step transposed weight copies): 64x64 tiles through LDS
+// out[c][r] = in[r][c] for a batch of [rows][cols] 16-bit matrices (the once-per-step transposed weight copies): 64x64 tiles through LDS.
+// rows % 8 == 0 and cols % 8 == 0 (every Linear of the model): 16-byte global loads and stores on both sides; the LDS tile is
+// [source column][source row] with the 8-row chunk index XOR-ed by (column >> 3), which spreads the eight lanes that scatter one
+// source row's chunks over eight banks (a plain 16-byte-aligned row stride puts them all on one).  Other shapes: 2-byte accesses.
 struct TrTable { const void* src[64]; void* dst[64]; int rows[64], cols[64], first[65]; int count; };
 __global__ __launch_bounds__(256) void transpose_batched_kernel(TrTable t) {
-  __shared__ unsigned short tile[64][66];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
   const int blk = blockIdx.x;
   int lo = 0, hi = t.count;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.first[mid] <= blk) lo = mid; else hi = mid; }
@@ -300,6 +303,27 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(TrTable t) {
   const int tr0 = (local / tc) * 64, tc0 = (local % tc) * 64;
   const unsigned short* s = (const unsigned short*)t.src[e];
   unsigned short* d = (unsigned short*)t.dst[e];
+  if (((R | C) & 7) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    for (int i = threadIdx.x; i < 512; i += 256) {          // 64 source rows x 8 chunks of 8 columns
+      const int r = i >> 3, ch = i & 7;
+      if (tr0 + r < R && tc0 + ch * 8 < C) {
+        const us8 v = *reinterpret_cast<const us8*>(s + (size_t)(tr0 + r) * C + tc0 + ch * 8);
+        const int pos = r ^ (ch << 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[ch * 8 + j][pos] = v[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {          // 64 destination rows (source columns) x 8 chunks of 8 source rows
+      const int c = i >> 3, q = i & 7;
+      if (tc0 + c < C && tr0 + q * 8 < R) {
+        const us8 v = *reinterpret_cast<const us8*>(&tile[c][(q ^ (c >> 3)) * 8]);
+        *reinterpret_cast<us8*>(d + (size_t)(tc0 + c) * R + tr0 + q * 8) = v;
+      }
+    }
+    return;
+  }
   const int x = threadIdx.x & 63, y0 = threadIdx.x >> 6;
   for (int y = y0; y < 64; y += 4)
     if (tr0 + y < R && tc0 + x < C) tile[y][x] = s[(size_t)(tr0 + y) * C + tc0 + x];

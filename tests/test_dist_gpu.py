@@ -273,7 +273,7 @@ def test_bench_control_flow_two_ranks_one_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DGTD_DIST_BACKEND="gloo", DGTD_GEMM_CANDIDATES="2")
+    env = dict(os.environ, DGTD_DIST_BACKEND="gloo", DGTD_GEMM_CANDIDATES="2", OMP_NUM_THREADS="4")    # two ranks on one box's cores
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -267,6 +267,25 @@ def test_ca_gate_matches_calayer_plus_residual(dgtd, B, C, H, W, dtype):
     torch.testing.assert_close(hw2, gw2, atol=wtol * gw2.abs().max().item() + 1e-6, rtol=wtol)
 
 
+@pytest.mark.parametrize("dtype", HALVES, ids=str)
+def test_transpose_batched_mixed_shapes(dgtd, dtype):
+    """dgtd_transpose_batched (the once-per-step transposed weight copies of csrc/gemm.hip): 70 matrices in one call (two launches of
+    <= 64), full and partial 64x64 tiles on the 16-byte path, shapes that are not multiples of 8 and a misaligned view on the 2-byte path."""
+    import ctypes as C
+    L = dgtd._lib
+    shapes = [(320, 1280), (1280, 320), (64, 64), (8, 8), (72, 40), (512, 2048), (30, 50), (7, 64), (64, 9)] + [(128, 64 + 8 * i) for i in range(61)]
+    srcs = [_rand(r, c, seed=10 + i).to(dtype) for i, (r, c) in enumerate(shapes)]
+    odd = _rand(16 * 24 + 1, seed=99).to(dtype)[1:].view(16, 24)           # 2 bytes off a 16-byte boundary
+    srcs.append(odd)
+    dsts = [torch.full((t.shape[1], t.shape[0]), float("nan"), device="cuda", dtype=dtype) for t in srcs]
+    n = len(srcs)
+    P, I = C.c_void_p * n, C.c_int * n
+    L.call("dgtd_transpose_batched", P(*[t.data_ptr() for t in srcs]), P(*[t.data_ptr() for t in dsts]), I(*[t.shape[0] for t in srcs]),
+           I(*[t.shape[1] for t in srcs]), n, L.dtype_code(srcs[0]), L.stream_ptr())
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b, a.t().contiguous()), tuple(a.shape)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(8, 96, 64, 64), (3, 64, 12, 20), (40, 32, 16, 16)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=str)
 def test_ca_gate_bwd_rows_sum_to_the_batched_gradients(dgtd, B, C, H, W, dtype):

@@ -449,7 +449,7 @@ def test_graphed_step_with_forced_allreduce(dtype):
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
     tol = 1e-4 if dtype == "f32" else 2e-2
-    for mode in ("fused", "hooks", "split"):
+    for mode in (("fused", "hooks", "split") if dtype == "f32" else ("fused", "split")):
         got, want = out[mode]["losses"], out["eager"]["losses"]
         print(f"[{dtype} {mode}] losses {got} vs eager {want}; max weight diff {out[mode]['max_weight_diff']:.2e}, elements off {out[mode]['elements_off']}")
         assert out[mode]["steps"] == 3
