@@ -10,6 +10,7 @@
 //   fwd   : per (map k, sample b): A = sum w*bce, I = sum w*sig*gt, U = sum w*(sig+gt); per b: W = sum w   (wave shuffles + atomics)
 //   bwd   : gather per low-res pixel over the <= 16x16 label pixels it touches (transpose of the bilinear sampling)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ 
       const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
 #pragma unroll
       for (int k = 0; k < NMAP; ++k) {
+        if (mix[k] == 0.f) continue;                          // a map the loss does not weigh has a zero gradient (stage 0: 0.2 * 0, cod.py:139)
         const float* m = lo + ((size_t)k * B + b) * hs * hs;
         const float z = w00 * m[y0 * hs + x0] + w01 * m[y0 * hs + x1] + w10 * m[y1 * hs + x0] + w11 * m[y1 * hs + x1];
         const float e = expf(-fabsf(z));
@@ -163,6 +165,81 @@ __global__ __launch_bounds__(64) void loss_bwd_kernel(const float* __restrict__ 
   for (int k = 0; k < NMAP; ++k) {
     const float v = wave_sum(acc[k]);
     if (lane == 0) dlo[((size_t)k * B + b) * hs * hs + cell] = gout[0] * mix[k] / (float)B * v;
+  }
+}
+
+// The same for the x8 up-sampling the model uses (S == 8 hs, cod.py:796 / :806), tiled: a workgroup owns 8 x 8 cells.  The label pixels
+// that touch them are the 72 x 72 block starting 4 pixels before the tile; the derivative dL_k/dz of every such pixel is evaluated ONCE
+// (the gather above evaluates every pixel once per cell it touches: 4x, behind 9 taps of index arithmetic) into LDS, then four threads
+// per cell sum their 16 x 16 window with the bilinear weights - the same weights, the same order per cell on every run (deterministic).
+constexpr int LT = 8, LP = LT * 8 + 8;             // cells per tile side, pixels per tile side (72)
+__global__ __launch_bounds__(256) void loss_bwd_tiled_kernel(const float* __restrict__ lo, const float* __restrict__ gt,
+                                                             const float* __restrict__ weit, const float* __restrict__ sums,
+                                                             const float* __restrict__ wsum, const float* __restrict__ mix,
+                                                             const float* __restrict__ gout, float* __restrict__ dlo, int B, int S, int hs) {
+  __shared__ float g[LP][LP + 1];
+  const int b = blockIdx.z, cy0 = blockIdx.y * LT, cx0 = blockIdx.x * LT, tid = threadIdx.x;
+  const int py0 = cy0 * 8 - 4, px0 = cx0 * 8 - 4;
+  const float scale = (float)hs / (float)S, Wb = wsum[b];
+  const size_t plane = (size_t)b * S * S;
+  const int cell = tid >> 2, part = tid & 3, cy = cy0 + cell / LT, cx = cx0 + cell % LT;
+  // the cell's window = pixel rows 8 cy - 4 .. 8 cy + 11 = tile rows 8 (cy - cy0) .. + 15 (columns likewise); this thread takes 4 of the 16
+  // rows.  Its bilinear weights are the same for every map (0 outside the image or where the pixel does not touch the cell)
+  const int ry = (cy - cy0) * 8, rx = (cx - cx0) * 8;
+  float wys[4], wxs[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = py0 + ry + part * 4 + r;
+    int y0, y1; float ly;
+    bil_src(y, scale, hs, y0, y1, ly);
+    wys[r] = (y >= 0 && y < S) ? (y0 == cy ? 1.f - ly : 0.f) + (y1 == cy ? ly : 0.f) : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int x = px0 + rx + c;
+    int x0, x1; float lx;
+    bil_src(x, scale, hs, x0, x1, lx);
+    wxs[c] = (x >= 0 && x < S) ? (x0 == cx ? 1.f - lx : 0.f) + (x1 == cx ? lx : 0.f) : 0.f;
+  }
+  for (int k = 0; k < NMAP; ++k) {
+    const float mk = mix[k];
+    float acc = 0.f;
+    if (mk != 0.f) {                                 // a map the loss does not weigh has a zero gradient (stage 0: 0.2 * 0, cod.py:139)
+      const float* p3 = sums + ((size_t)k * B + b) * 3;
+      const float Nn = p3[1] + 1.f, Dn = p3[2] - p3[1] + 1.f;
+      const float* m = lo + ((size_t)k * B + b) * hs * hs;
+      for (int p = tid; p < LP * LP; p += 256) {      // (the taps are recomputed per map: a few integer ops against 20 live arrays of 21)
+        const int py = p / LP, px = p - py * LP, y = py0 + py, x = px0 + px;
+        float gv = 0.f;
+        if (y >= 0 && y < S && x >= 0 && x < S) {
+          int y0, y1, x0, x1; float ly, lx;
+          bil_src(y, scale, hs, y0, y1, ly);
+          bil_src(x, scale, hs, x0, x1, lx);
+          const float w = weit[plane + (size_t)y * S + x], t = gt[plane + (size_t)y * S + x];
+          const float z = (1.f - ly) * (1.f - lx) * m[y0 * hs + x0] + (1.f - ly) * lx * m[y0 * hs + x1] + ly * (1.f - lx) * m[y1 * hs + x0] +
+                          ly * lx * m[y1 * hs + x1];
+          const float e = expf(-fabsf(z));
+          const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+          const float ds = sg * (1.f - sg);
+          gv = w * (sg - t) / Wb - w * ds * (t * Dn - Nn * (1.f - t)) / (Dn * Dn);
+        }
+        g[py][px] = gv;
+      }
+      __syncthreads();
+      if (cy < hs && cx < hs) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float row = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) row += wxs[c] * g[ry + part * 4 + r][rx + c];
+          acc += wys[r] * row;
+        }
+      }
+      __syncthreads();                               // g is rewritten for the next map
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && cy < hs && cx < hs) dlo[((size_t)k * B + b) * hs * hs + cy * hs + cx] = gout[0] * mk / (float)B * acc;
   }
 }
 
@@ -292,7 +369,13 @@ extern "C" int dgtd_seg_loss_bwd(const float* lo, const float* label, const floa
   const float* weit = (const float*)workspace;
   const float* sums = weit + (size_t)B * S * S;
   const float* wsum = sums + (size_t)NMAP * B * 3;
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(hs * hs, B), dim3(64), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
+  static const bool tiled = !(getenv("DGTD_LOSS_BWD_TILED") && getenv("DGTD_LOSS_BWD_TILED")[0] == '0');
+  if (tiled && S == 8 * hs && B <= 65535) {          // the model's x8 up-sampling: every pixel's derivative evaluated once per tile
+    const int tiles = (hs + LT - 1) / LT;
+    hipLaunchKernelGGL(loss_bwd_tiled_kernel, dim3(tiles, tiles, B), dim3(256), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
+  } else {
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(hs * hs, B), dim3(64), 0, (hipStream_t)s, lo, label, weit, sums, wsum, mix, gout, dlo, B, S, hs);
+  }
   DGTD_CHECK_LAUNCH("loss_bwd");
   return 0;
 }

@@ -198,7 +198,7 @@ def test_linear_with_colsum_bias_grad(dgtd, rows, K, N, dtype):
 
 
 # ---------------------------------------------------------------------------------------------- fused structure loss
-@pytest.mark.parametrize("S,hs,B", [(64, 8, 2), (96, 12, 3), (512, 64, 2)])
+@pytest.mark.parametrize("S,hs,B", [(64, 8, 2), (96, 12, 3), (512, 64, 2), (64, 16, 2), (160, 20, 1)])     # x8 (tiled backward), x4 (generic gather)
 def test_seg_loss_vs_oracle(dgtd, S, hs, B):
     from oracle import cod_cpu
     g = torch.Generator().manual_seed(S)
