@@ -331,7 +331,10 @@ extern "C" int dgtd_ssim_value(const float* x_hp, const float* image, float* out
   const long n = (long)B * C * S * S;
   hipLaunchKernelGGL(ssim_minmax_kernel, dim3((int)std::min<long>(cdiv(n, 1024), 512)), dim3(256), 0, st, x_hp, mm, n);
   DGTD_CHECK_LAUNCH("ssim_minmax");
-  hipLaunchKernelGGL(ssim_map_kernel, dim3((int)std::min<long>(cdiv((long)S * S, 256), 256), B * C), dim3(256), 0, st, x_hp, image, (const unsigned*)mm, acc, S);
+  // one fp64 atomic per workgroup on ONE address: 6144 of them (256 slices x 24 planes) serialised into most of the kernel's 82 us;
+  // 96 slices per plane (2304 atomics) measured best: 105 -> 66 us for the whole value (tools/ssim_time.py)
+  static const int slices = getenv("DGTD_SSIM_SLICES") ? atoi(getenv("DGTD_SSIM_SLICES")) : 96;
+  hipLaunchKernelGGL(ssim_map_kernel, dim3((int)std::max<long>(1, std::min<long>(cdiv((long)S * S, 256), slices)), B * C), dim3(256), 0, st, x_hp, image, (const unsigned*)mm, acc, S);
   DGTD_CHECK_LAUNCH("ssim_map");
   hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1), 0, st, (const double*)acc, out, 1.0 / (double)n);
   DGTD_CHECK_LAUNCH("ssim_finish");
